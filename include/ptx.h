@@ -1,0 +1,194 @@
+/*
+ * ptx.h -- C ABI of the MI355X (gfx950) wavefront path-tracing backend that
+ * replaces AHL00/path_tracer's Vulkan ray-tracing render loop.
+ *
+ * The reference has no FFI for this path (its only FFI is the unused nrd-sys
+ * crate); each entry point below carries exactly the payload the reference's
+ * Rust host already produces at the cited call site, so a Rust `extern "C"`
+ * block binds it unchanged.  All structs are byte-identical
+ * to /root/reference/src/shaders/shared.glsl:1-60.
+ *
+ * Conventions: every call returns a ptx_status (0 = ok) -- no exception or
+ * panic crosses the ABI; caller-owned inputs are copied before the call
+ * returns; a context is not thread-safe, distinct contexts may be driven from
+ * distinct threads; there is no CPU fallback (ptx_create fails without a HIP
+ * device).
+ */
+#ifndef PTX_H
+#define PTX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PTX_OK = 0,
+    PTX_ERR_INVALID = 1,    /* bad argument / out-of-range offset */
+    PTX_ERR_CAPACITY = 2,   /* a fixed-capacity scene buffer is full (the reference panics: scene/mod.rs:281-283,347-349,412-414; renderer.rs:899-901) */
+    PTX_ERR_HIP = 3,        /* HIP runtime error, text in ptx_last_error */
+    PTX_ERR_STATE = 4       /* call order violated (e.g. render before resize/set_instances) */
+} ptx_status;
+
+/* shared.glsl:1-6, renderer.rs:91-111 -- 48 B */
+typedef struct {
+    float position[3]; float _pad0;
+    float normal[3];   float _pad1;
+    float uv[2];
+    float padding[2];
+} ptx_vertex;
+
+/* shared.glsl:8-15, renderer.rs:932-939 -- 24 B */
+typedef struct {
+    uint32_t vertex_offset, vertex_count, material_offset, padding, index_offset, index_count;
+} ptx_offsets;
+
+/* shared.glsl:27-36, material.rs:70-76 -- 32 B */
+typedef struct {
+    float base_color[4];
+    uint32_t has_base_texture;
+    uint32_t base_texture_indice;
+    float metallic;
+    float roughness;
+} ptx_material;
+
+/* shared.glsl:17-21, renderer.rs:1011-1015 -- three column-major mat4, 192 B */
+typedef struct {
+    float view_proj[16];
+    float view_inverse[16];
+    float proj_inverse[16];
+} ptx_camera;
+
+/* shared.glsl:51-60, renderer.rs:1003-1010 -- 32 B */
+typedef struct {
+    uint32_t samples_per_pixel;   /* sent by the reference, unused by its shaders */
+    uint32_t seed;
+    uint32_t accumulated_count;
+    float z_near, z_far;
+    uint32_t padding[3];
+} ptx_uniforms;
+
+/* One TLAS instance + its Offsets row (renderer.rs:927-954): xform is the 3x4
+ * row-major matrix of mat4_to_as_instance_array (renderer.rs:1416-1423); the
+ * array index is gl_InstanceCustomIndexEXT.  76 B. */
+typedef struct {
+    float xform[3][4];
+    uint32_t geometry;            /* handle from ptx_create_geometry */
+    ptx_offsets off;
+} ptx_instance;
+
+/* Constants the reference hard-codes, with its values as defaults
+ * (ptx_default_params): rgen.glsl:18,37-38; rchit.glsl:242. */
+typedef struct {
+    uint32_t max_depth;           /* 16 */
+    float t_min;                  /* 0.001 */
+    float t_max;                  /* 10000 */
+    float normal_eps;             /* 0.001 */
+    uint32_t rng_sample_offset;   /* added to accumulated_count for the RNG only (spp partition across GPUs); 0 */
+    uint32_t flags;               /* reserved, 0 */
+    uint32_t _pad[2];
+} ptx_render_params;
+
+/* Fixed buffer capacities; defaults are the reference's (scene/mod.rs:48-54, renderer.rs:180). */
+typedef struct {
+    uint64_t max_vertices;        /* 2 500 000 */
+    uint64_t max_indices;         /* 5 000 000 */
+    uint32_t max_materials;       /* 10 000 */
+    uint32_t max_offsets;         /* 10 000 (instances) */
+    uint32_t max_textures;        /* 5 000 */
+    uint32_t _pad;
+} ptx_limits;
+
+typedef enum {
+    PTX_IMAGE_ALBEDO = 0,         /* RGBA32F running mean, A = 1   (renderer.rs:476-495) */
+    PTX_IMAGE_NORMAL = 1,         /* RGBA32F first-hit normal, A=1 (renderer.rs:497-508) */
+    PTX_IMAGE_DEPTH = 2,          /* R32F normalised depth         (renderer.rs:510-531) */
+    PTX_IMAGE_PRIMARY_ID = 3      /* 2 x u32 (instance, primitive) of the first hit, 0xFFFFFFFF on miss -- build extension for the parity check */
+} ptx_image_kind;
+
+typedef struct {
+    uint64_t rays;                /* path segments traced since the last ptx_reset_stats */
+    uint64_t hits;
+    uint64_t samples;             /* pixel-samples accumulated */
+    uint64_t extend_launches;     /* launches of the traversal kernel */
+    double extend_ms;             /* their summed GPU time (HIP events on the context stream; only while profiling is on) */
+    double shade_ms;
+    double total_ms;              /* GPU time of all render calls while profiling is on */
+    uint64_t bvh_nodes, bvh_triangles, bvh_bytes;
+    uint32_t bvh_depth, _pad;
+} ptx_stats;
+
+typedef struct ptx_context ptx_context;
+
+/* Renderer::new (renderer.rs:183).  One context per GPU. */
+int ptx_create(int device_ordinal, ptx_context **ctx);
+int ptx_create_with_limits(int device_ordinal, const ptx_limits *limits, ptx_context **ctx);
+int ptx_destroy(ptx_context *ctx);
+void ptx_default_limits(ptx_limits *limits);
+void ptx_default_params(ptx_render_params *params);
+
+/* Scene::add_vertices / add_indices / add_material (scene/mod.rs:270,405,340):
+ * bump-append into the shared buffers, returning the element offset. */
+int ptx_add_vertices(ptx_context *ctx, const ptx_vertex *vertices, uint64_t n, uint64_t *first);
+int ptx_add_indices(ptx_context *ctx, const uint32_t *indices, uint64_t n, uint64_t *first);
+int ptx_add_material(ptx_context *ctx, const ptx_material *material, uint32_t *index);
+
+/* Renderer::add_texture after Texture::from_gltf (renderer.rs:878, graphics.rs:383):
+ * decoded 8-bit RGBA texels, row 0 first; srgb=1 is R8G8B8A8_SRGB.  Sampled as the
+ * reference's default sampler does: nearest, clamp-to-edge, LOD 0.  The caller keeps
+ * the ident -> index cache (renderer.rs:867-873). */
+int ptx_add_texture(ptx_context *ctx, const uint8_t *rgba8, uint32_t width, uint32_t height, int srgb,
+                    uint32_t *bindless_index);
+
+/* Geometry::create's BLAS build (geometry/mod.rs:54-103): registers a vertex/index
+ * range of the shared buffers as a geometry and validates its indices. */
+int ptx_create_geometry(ptx_context *ctx, uint64_t first_vertex, uint64_t n_vertices, uint64_t first_index,
+                        uint64_t n_indices, uint32_t *geometry);
+
+/* The per-frame instance list + TLAS build of record_commands (renderer.rs:912-961).
+ * Rebuilds the acceleration structure; marks the accumulation dirty. */
+int ptx_set_instances(ptx_context *ctx, const ptx_instance *instances, uint32_t n);
+
+/* Renderer::resize_render_buffer (renderer.rs:583): reallocates the three images, resets accumulation. */
+int ptx_resize(ptx_context *ctx, uint32_t width, uint32_t height);
+
+/* One trace_rays dispatch (renderer.rs:1002-1067) = 1 sample per pixel with the given
+ * seed / accumulated_count.  Asynchronous on the context's stream. */
+int ptx_render(ptx_context *ctx, const ptx_uniforms *uniforms, const ptx_camera *camera,
+               const ptx_render_params *params);
+
+/* Build extension: n_samples consecutive frames in one call, frame i using
+ * accumulated_count = uniforms->accumulated_count + i.  Bit-identical to n_samples
+ * ptx_render calls. */
+int ptx_render_batch(ptx_context *ctx, const ptx_uniforms *uniforms, const ptx_camera *camera,
+                     const ptx_render_params *params, uint32_t n_samples);
+
+/* Image readback (renderer.rs:668-742).  Synchronises the stream.  Row 0 = top of the view.
+ * bytes must equal width*height*{16,16,4,8}. */
+int ptx_read_image(ptx_context *ctx, int kind, void *dst, uint64_t bytes);
+
+/* Uploads an RGBA32F image into the accumulation buffer (resume from a dump, or the
+ * combined result of a multi-GPU reduce). */
+int ptx_write_albedo(ptx_context *ctx, const void *src, uint64_t bytes);
+
+/* Multi-GPU (build extension).  One-process-per-GPU hosts (torch.distributed
+ * over RCCL) use the device-pointer form: the albedo buffer scaled by `scale` is written to
+ * / read from caller-owned DEVICE memory on the context's device, ordered on the context's
+ * stream, so the caller can all-reduce it in place. */
+int ptx_export_albedo_device(ptx_context *ctx, void *device_dst, uint64_t bytes, float scale);
+int ptx_import_albedo_device(ptx_context *ctx, const void *device_src, uint64_t bytes, float scale);
+/* Single-process hosts: sum the accumulation buffers of n contexts (one per GPU) into
+ * ctxs[root] with an RCCL reduce over xGMI, then scale by 1/n. */
+int ptx_reduce_accumulation(ptx_context **ctxs, int n, int root);
+
+int ptx_synchronize(ptx_context *ctx);
+int ptx_set_profiling(ptx_context *ctx, int enabled);   /* HIP-event timing of each stage launch */
+int ptx_get_stats(ptx_context *ctx, ptx_stats *stats);  /* synchronises */
+int ptx_reset_stats(ptx_context *ctx);
+const char *ptx_last_error(ptx_context *ctx);           /* ctx may be NULL: last error of ptx_create on this thread */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,53 @@
+"""Builds path_tracer_amd/libptx_amd.so (HIP kernels + C ABI) for gfx950 with hipcc.
+
+hipcc cross-compiles without a GPU.  The library is built in-tree so that it travels with the
+repository snapshot to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libptx_amd.so")
+SOURCES = ["ptx_api.cpp", "ptx_kernels.hip", "bvh_build.cpp", "ptx_rccl.cpp"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: shading / triangle-test arithmetic must round exactly like the CPU oracle's.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+         "-Wall", "-Wno-unused-function", "-x", "hip"]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "ptx.h"), __file__]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+    for src in SOURCES:
+        obj = os.path.join(HERE, "_build", src + ".o")
+        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"]
+    if verbose:
+        print(" ".join(link))
+    subprocess.check_call(link)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv, verbose=True)
+    print(LIB)

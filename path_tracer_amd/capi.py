@@ -1,0 +1,237 @@
+"""ctypes binding of libptx_amd.so (include/ptx.h).  Thin: one method per C entry point.
+
+There is no CPU fallback: a missing library or a failed ptx_create raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptx_amd.so")
+
+PTX_OK, PTX_ERR_INVALID, PTX_ERR_CAPACITY, PTX_ERR_HIP, PTX_ERR_STATE = range(5)
+IMAGE_ALBEDO, IMAGE_NORMAL, IMAGE_DEPTH, IMAGE_PRIMARY_ID = range(4)
+
+VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("_p0", "<f4"), ("normal", "<f4", 3), ("_p1", "<f4"),
+                         ("uv", "<f4", 2), ("padding", "<f4", 2)])
+MATERIAL_DTYPE = np.dtype([("base_color", "<f4", 4), ("has_base_texture", "<u4"), ("base_texture_indice", "<u4"),
+                           ("metallic", "<f4"), ("roughness", "<f4")])
+OFFSETS_DTYPE = np.dtype([("vertex_offset", "<u4"), ("vertex_count", "<u4"), ("material_offset", "<u4"),
+                          ("padding", "<u4"), ("index_offset", "<u4"), ("index_count", "<u4")])
+INSTANCE_DTYPE = np.dtype([("xform", "<f4", (3, 4)), ("geometry", "<u4"), ("off", OFFSETS_DTYPE)])
+
+
+class Camera(C.Structure):
+    _fields_ = [("view_proj", C.c_float * 16), ("view_inverse", C.c_float * 16), ("proj_inverse", C.c_float * 16)]
+
+
+class Uniforms(C.Structure):
+    _fields_ = [("samples_per_pixel", C.c_uint32), ("seed", C.c_uint32), ("accumulated_count", C.c_uint32),
+                ("z_near", C.c_float), ("z_far", C.c_float), ("padding", C.c_uint32 * 3)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("max_depth", C.c_uint32), ("t_min", C.c_float), ("t_max", C.c_float), ("normal_eps", C.c_float),
+                ("rng_sample_offset", C.c_uint32), ("flags", C.c_uint32), ("_pad", C.c_uint32 * 2)]
+
+
+class Limits(C.Structure):
+    _fields_ = [("max_vertices", C.c_uint64), ("max_indices", C.c_uint64), ("max_materials", C.c_uint32),
+                ("max_offsets", C.c_uint32), ("max_textures", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("hits", C.c_uint64), ("samples", C.c_uint64),
+                ("extend_launches", C.c_uint64), ("extend_ms", C.c_double), ("shade_ms", C.c_double),
+                ("total_ms", C.c_double), ("bvh_nodes", C.c_uint64), ("bvh_triangles", C.c_uint64),
+                ("bvh_bytes", C.c_uint64), ("bvh_depth", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+EXPORTS = [
+    "ptx_create", "ptx_create_with_limits", "ptx_destroy", "ptx_default_limits", "ptx_default_params",
+    "ptx_add_vertices", "ptx_add_indices", "ptx_add_material", "ptx_add_texture", "ptx_create_geometry",
+    "ptx_set_instances", "ptx_resize", "ptx_render", "ptx_render_batch", "ptx_read_image", "ptx_write_albedo",
+    "ptx_export_albedo_device", "ptx_import_albedo_device", "ptx_reduce_accumulation", "ptx_synchronize",
+    "ptx_set_profiling", "ptx_get_stats", "ptx_reset_stats", "ptx_last_error",
+]
+
+_lib = None
+
+
+class PtxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ptx error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """Loads libptx_amd.so.  Raises if it has not been built -- the product never falls back to a CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("%s is missing: run `python -m path_tracer_amd.build` (hipcc, gfx950)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.ptx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.ptx_create_with_limits.argtypes = [C.c_int, C.POINTER(Limits), C.POINTER(vp)]
+    L.ptx_destroy.argtypes = [vp]
+    L.ptx_default_limits.argtypes = [C.POINTER(Limits)]
+    L.ptx_default_limits.restype = None
+    L.ptx_default_params.argtypes = [C.POINTER(RenderParams)]
+    L.ptx_default_params.restype = None
+    L.ptx_add_vertices.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.ptx_add_indices.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.ptx_add_material.argtypes = [vp, vp, C.POINTER(C.c_uint32)]
+    L.ptx_add_texture.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
+    L.ptx_create_geometry.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
+    L.ptx_set_instances.argtypes = [vp, vp, C.c_uint32]
+    L.ptx_resize.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.ptx_render.argtypes = [vp, C.POINTER(Uniforms), C.POINTER(Camera), C.POINTER(RenderParams)]
+    L.ptx_render_batch.argtypes = [vp, C.POINTER(Uniforms), C.POINTER(Camera), C.POINTER(RenderParams), C.c_uint32]
+    L.ptx_read_image.argtypes = [vp, C.c_int, vp, C.c_uint64]
+    L.ptx_write_albedo.argtypes = [vp, vp, C.c_uint64]
+    L.ptx_export_albedo_device.argtypes = [vp, vp, C.c_uint64, C.c_float]
+    L.ptx_import_albedo_device.argtypes = [vp, vp, C.c_uint64, C.c_float]
+    L.ptx_reduce_accumulation.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+    L.ptx_synchronize.argtypes = [vp]
+    L.ptx_set_profiling.argtypes = [vp, C.c_int]
+    L.ptx_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.ptx_reset_stats.argtypes = [vp]
+    L.ptx_last_error.argtypes = [vp]
+    L.ptx_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def default_params(**kw):
+    p = RenderParams()
+    load().ptx_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def default_limits(**kw):
+    l = Limits()
+    load().ptx_default_limits(C.byref(l))
+    for k, v in kw.items():
+        setattr(l, k, v)
+    return l
+
+
+class Context:
+    """One ptx_context (one GPU)."""
+
+    def __init__(self, device=0, limits=None):
+        self._L = load()
+        h = C.c_void_p()
+        rc = (self._L.ptx_create_with_limits(device, C.byref(limits), C.byref(h)) if limits is not None
+              else self._L.ptx_create(device, C.byref(h)))
+        if rc:
+            raise PtxError(rc, self._L.ptx_last_error(None).decode())
+        self.handle = h
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._L.ptx_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc:
+            raise PtxError(rc, self._L.ptx_last_error(self.handle).decode())
+
+    def add_vertices(self, v):
+        v = np.ascontiguousarray(v, dtype=VERTEX_DTYPE)
+        first = C.c_uint64()
+        self._check(self._L.ptx_add_vertices(self.handle, v.ctypes.data, len(v), C.byref(first)))
+        return first.value
+
+    def add_indices(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        first = C.c_uint64()
+        self._check(self._L.ptx_add_indices(self.handle, idx.ctypes.data, len(idx), C.byref(first)))
+        return first.value
+
+    def add_material(self, m):
+        m = np.ascontiguousarray(m, dtype=MATERIAL_DTYPE).reshape(1)
+        out = C.c_uint32()
+        self._check(self._L.ptx_add_material(self.handle, m.ctypes.data, C.byref(out)))
+        return out.value
+
+    def add_texture(self, rgba8, srgb=True):
+        a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        assert a.ndim == 3 and a.shape[2] == 4
+        out = C.c_uint32()
+        self._check(self._L.ptx_add_texture(self.handle, a.ctypes.data, a.shape[1], a.shape[0], int(bool(srgb)),
+                                            C.byref(out)))
+        return out.value
+
+    def create_geometry(self, first_vertex, n_vertices, first_index, n_indices):
+        out = C.c_uint32()
+        self._check(self._L.ptx_create_geometry(self.handle, first_vertex, n_vertices, first_index, n_indices,
+                                                C.byref(out)))
+        return out.value
+
+    def set_instances(self, inst):
+        inst = np.ascontiguousarray(inst, dtype=INSTANCE_DTYPE)
+        self._check(self._L.ptx_set_instances(self.handle, inst.ctypes.data, len(inst)))
+
+    def resize(self, width, height):
+        self._check(self._L.ptx_resize(self.handle, width, height))
+        self.width, self.height = width, height
+
+    def render(self, uniforms, camera, params=None):
+        self._check(self._L.ptx_render(self.handle, C.byref(uniforms), C.byref(camera),
+                                       C.byref(params) if params is not None else None))
+
+    def render_batch(self, uniforms, camera, n_samples, params=None):
+        self._check(self._L.ptx_render_batch(self.handle, C.byref(uniforms), C.byref(camera),
+                                             C.byref(params) if params is not None else None, n_samples))
+
+    def read_image(self, kind):
+        h, w = self.height, self.width
+        if kind in (IMAGE_ALBEDO, IMAGE_NORMAL):
+            out = np.empty((h, w, 4), dtype=np.float32)
+        elif kind == IMAGE_DEPTH:
+            out = np.empty((h, w), dtype=np.float32)
+        else:
+            out = np.empty((h, w, 2), dtype=np.uint32)
+        self._check(self._L.ptx_read_image(self.handle, kind, out.ctypes.data, out.nbytes))
+        return out
+
+    def write_albedo(self, img):
+        a = np.ascontiguousarray(img, dtype=np.float32)
+        self._check(self._L.ptx_write_albedo(self.handle, a.ctypes.data, a.nbytes))
+
+    def export_albedo_device(self, device_ptr, nbytes, scale=1.0):
+        self._check(self._L.ptx_export_albedo_device(self.handle, device_ptr, nbytes, scale))
+
+    def import_albedo_device(self, device_ptr, nbytes, scale=1.0):
+        self._check(self._L.ptx_import_albedo_device(self.handle, device_ptr, nbytes, scale))
+
+    def synchronize(self):
+        self._check(self._L.ptx_synchronize(self.handle))
+
+    def set_profiling(self, on):
+        self._check(self._L.ptx_set_profiling(self.handle, int(bool(on))))
+
+    def stats(self):
+        s = Stats()
+        self._check(self._L.ptx_get_stats(self.handle, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_ if not k.startswith("_")}
+
+    def reset_stats(self):
+        self._check(self._L.ptx_reset_stats(self.handle))
+
+
+def reduce_accumulation(contexts, root=0):
+    L = load()
+    arr = (C.c_void_p * len(contexts))(*[c.handle for c in contexts])
+    rc = L.ptx_reduce_accumulation(arr, len(contexts), root)
+    if rc:
+        raise PtxError(rc, L.ptx_last_error(contexts[root].handle).decode())

@@ -1,0 +1,287 @@
+// bvh_build.cpp -- host builder: binned-SAH BVH2 -> greedy collapse to 8-wide -> quantise.
+// Replaces the driver-side BLAS/TLAS builds of the reference (scene/geometry/mod.rs:136-278,
+// renderer.rs:1196-1388).  Plain C++17, no HIP.
+#include "bvh8.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <future>
+#include <limits>
+
+namespace ptx {
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset()
+    {
+        for (int a = 0; a < 3; ++a) { lo[a] = std::numeric_limits<float>::infinity(); hi[a] = -lo[a]; }
+    }
+    void grow(const Box &b)
+    {
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); }
+    }
+    float half_area() const
+    {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Node2 {
+    Box box;
+    uint32_t left = 0, right = 0;   // children (inner)
+    uint32_t first = 0, count = 0;  // leaf range in `order` (count > 0 => leaf)
+};
+
+struct Builder2 {
+    const Box *tri_box;
+    const float *centroid;            // 3 per triangle
+    std::vector<uint32_t> order;
+    std::vector<Node2> nodes;
+    std::atomic<uint32_t> n_nodes{0};
+
+    static constexpr int kBins = 16;
+    static constexpr uint32_t kMaxLeaf = 3;
+
+    uint32_t alloc2() { return n_nodes.fetch_add(2); }
+
+    void build(uint32_t node, uint32_t first, uint32_t count, int spawn_depth)
+    {
+        Node2 &n = nodes[node];
+        Box cb; cb.reset(); n.box.reset();
+        for (uint32_t i = first; i < first + count; ++i) {
+            uint32_t t = order[i];
+            n.box.grow(tri_box[t]);
+            for (int a = 0; a < 3; ++a) {
+                cb.lo[a] = std::min(cb.lo[a], centroid[t * 3 + a]);
+                cb.hi[a] = std::max(cb.hi[a], centroid[t * 3 + a]);
+            }
+        }
+        if (count == 1) { n.first = first; n.count = 1; return; }
+
+        // binned SAH over the three axes
+        float best_cost = std::numeric_limits<float>::infinity();
+        int best_axis = -1, best_bin = -1;
+        for (int a = 0; a < 3; ++a) {
+            float ext = cb.hi[a] - cb.lo[a];
+            if (!(ext > 0.0f)) continue;
+            Box bins[kBins]; uint32_t cnt[kBins];
+            for (int b = 0; b < kBins; ++b) { bins[b].reset(); cnt[b] = 0; }
+            float k = kBins / ext;
+            for (uint32_t i = first; i < first + count; ++i) {
+                uint32_t t = order[i];
+                int b = std::min(kBins - 1, std::max(0, (int)((centroid[t * 3 + a] - cb.lo[a]) * k)));
+                bins[b].grow(tri_box[t]); cnt[b]++;
+            }
+            float right_area[kBins]; uint32_t right_cnt[kBins];
+            Box acc; acc.reset(); uint32_t c = 0;
+            for (int b = kBins - 1; b > 0; --b) {
+                acc.grow(bins[b]); c += cnt[b];
+                right_area[b] = acc.half_area(); right_cnt[b] = c;
+            }
+            acc.reset(); c = 0;
+            for (int b = 0; b < kBins - 1; ++b) {
+                acc.grow(bins[b]); c += cnt[b];
+                if (c == 0 || right_cnt[b + 1] == 0) continue;
+                float cost = acc.half_area() * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+            }
+        }
+        // leaf if it is cheaper than the best split (cost model: node visit 1.5, triangle test 1)
+        if (count <= kMaxLeaf) {
+            float leaf_cost = (float)count * n.box.half_area();
+            if (best_axis < 0 || best_cost + 1.5f * n.box.half_area() >= leaf_cost) {
+                n.first = first; n.count = count; return;
+            }
+        }
+        uint32_t mid;
+        if (best_axis < 0) {
+            mid = first + count / 2;       // coincident centroids: split the range
+        } else {
+            float ext = cb.hi[best_axis] - cb.lo[best_axis];
+            float k = kBins / ext, lo = cb.lo[best_axis];
+            int a = best_axis, bb = best_bin;
+            auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
+                int b = std::min(kBins - 1, std::max(0, (int)((centroid[t * 3 + a] - lo) * k)));
+                return b <= bb;
+            });
+            mid = (uint32_t)(it - order.begin());
+            if (mid == first || mid == first + count) mid = first + count / 2;
+        }
+        uint32_t l = alloc2();
+        n.left = l; n.right = l + 1; n.count = 0;
+        uint32_t lc = mid - first, rc = count - lc;
+        if (spawn_depth > 0 && count > 8192) {
+            auto fut = std::async(std::launch::async, [=]() { build(l, first, lc, spawn_depth - 1); });
+            build(l + 1, mid, rc, spawn_depth - 1);
+            fut.get();
+        } else {
+            build(l, first, lc, 0);
+            build(l + 1, mid, rc, 0);
+        }
+    }
+};
+
+inline float step_of(uint8_t e) { uint32_t u = (uint32_t)e << 23; float f; memcpy(&f, &u, 4); return f; }
+
+}  // namespace
+
+bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
+{
+    out.nodes.clear(); out.tri_order.clear(); out.depth = 0;
+    if (n_tris == 0) return true;
+    if (n_tris > 1000000000u) return false;
+
+    // scene extent (finite triangles only; a triangle with a non-finite coordinate can never be
+    // hit by the triangle test, so it is simply left out of the tree)
+    std::vector<Box> tri_box(n_tris);
+    std::vector<float> centroid(n_tris * 3);
+    std::vector<uint32_t> order; order.reserve(n_tris);
+    float scene_ext = 0.0f;
+    {
+        Box sb; sb.reset();
+        for (size_t t = 0; t < n_tris; ++t) {
+            const float *v = verts + t * 9;
+            bool fin = true;
+            for (int k = 0; k < 9; ++k) fin = fin && std::isfinite(v[k]);
+            if (!fin) continue;
+            Box b; b.reset();
+            for (int k = 0; k < 3; ++k)
+                for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], v[k * 3 + a]); b.hi[a] = std::max(b.hi[a], v[k * 3 + a]); }
+            tri_box[t] = b; sb.grow(b);
+            order.push_back((uint32_t)t);
+        }
+        if (order.empty()) return true;
+        for (int a = 0; a < 3; ++a) scene_ext = std::max(scene_ext, sb.hi[a] - sb.lo[a]);
+    }
+    // Pad every triangle box so that box culling can never contradict the triangle test: the
+    // test's edge functions are exact only up to a few ulps of the coordinate magnitude.
+    for (uint32_t t : order) {
+        Box &b = tri_box[t];
+        for (int a = 0; a < 3; ++a) {
+            float m = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
+            float pad = 2e-5f * m + 1e-6f * scene_ext + 1e-30f;
+            b.lo[a] -= pad; b.hi[a] += pad;
+            centroid[(size_t)t * 3 + a] = 0.5f * b.lo[a] + 0.5f * b.hi[a];
+        }
+    }
+
+    Builder2 b2;
+    b2.tri_box = tri_box.data(); b2.centroid = centroid.data();
+    b2.order = std::move(order);
+    uint32_t n = (uint32_t)b2.order.size();
+    b2.nodes.resize((size_t)2 * n + 2);
+    b2.n_nodes = 1;
+    int spawn = 0;
+    while ((1 << spawn) < std::max(1, n_threads)) ++spawn;
+    b2.build(0, 0, n, spawn);
+
+    // ---- collapse to 8-wide, breadth-first so that a node's internal children are contiguous ----
+    struct Pending { uint32_t node2; uint32_t depth; };
+    std::vector<Pending> queue;
+    queue.push_back({0u, 1u});
+    out.nodes.resize(1);
+    out.tri_order.reserve(n);
+    for (size_t qi = 0; qi < queue.size(); ++qi) {
+        const Node2 &src = b2.nodes[queue[qi].node2];
+        uint32_t depth = queue[qi].depth;
+        out.depth = std::max(out.depth, depth);
+
+        uint32_t kids[8]; int nk = 0;
+        if (src.count > 0) {
+            kids[nk++] = queue[qi].node2;             // a leaf root becomes the single leaf slot
+        } else {
+            kids[nk++] = src.left; kids[nk++] = src.right;
+            for (;;) {                                // open the inner child of largest area
+                if (nk == 8) break;
+                int pick = -1; float best = -1.0f;
+                for (int i = 0; i < nk; ++i) {
+                    const Node2 &c = b2.nodes[kids[i]];
+                    if (c.count == 0 && c.box.half_area() > best) { best = c.box.half_area(); pick = i; }
+                }
+                if (pick < 0) break;
+                uint32_t open = kids[pick];
+                kids[pick] = b2.nodes[open].left;
+                kids[nk++] = b2.nodes[open].right;
+            }
+        }
+
+        // slot assignment: slot s is visited first by rays whose direction is negative exactly
+        // on the axes whose bit is set in s (bit2 = x, bit1 = y, bit0 = z), so it should hold the
+        // child lying furthest along ds(s) = (+1 where the bit is set, -1 elsewhere).
+        float center[3];
+        for (int a = 0; a < 3; ++a) center[a] = 0.5f * src.box.lo[a] + 0.5f * src.box.hi[a];
+        float cost[8][8];
+        for (int c = 0; c < nk; ++c) {
+            const Box &cbx = b2.nodes[kids[c]].box;
+            float d[3];
+            for (int a = 0; a < 3; ++a) d[a] = (0.5f * cbx.lo[a] + 0.5f * cbx.hi[a]) - center[a];
+            for (int s = 0; s < 8; ++s)
+                cost[c][s] = ((s & 4) ? d[0] : -d[0]) + ((s & 2) ? d[1] : -d[1]) + ((s & 1) ? d[2] : -d[2]);
+        }
+        int slot_child[8]; bool child_done[8] = {false};
+        for (int s = 0; s < 8; ++s) slot_child[s] = -1;
+        for (int it = 0; it < nk; ++it) {
+            float best = -std::numeric_limits<float>::infinity(); int bc = -1, bs = -1;
+            for (int c = 0; c < nk; ++c) {
+                if (child_done[c]) continue;
+                for (int s = 0; s < 8; ++s)
+                    if (slot_child[s] < 0 && cost[c][s] > best) { best = cost[c][s]; bc = c; bs = s; }
+            }
+            slot_child[bs] = bc; child_done[bc] = true;
+        }
+
+        Bvh8Node nd; memset(&nd, 0, sizeof nd);
+        for (int a = 0; a < 3; ++a) {
+            nd.p[a] = src.box.lo[a];
+            float ext = src.box.hi[a] - src.box.lo[a];
+            int e; float m = std::frexp(ext / 255.0f, &e);   // ext/255 = m * 2^e, m in [0.5,1)
+            (void)m;
+            int be = e + 127;                                // step = 2^e >= ext/255
+            be = std::min(254, std::max(1, be));
+            while (be < 254 && !(nd.p[a] + step_of((uint8_t)be) * 255.0f >= src.box.hi[a])) ++be;
+            nd.e[a] = (uint8_t)be;
+        }
+        nd.child_base = (uint32_t)out.nodes.size();
+        nd.tri_base = (uint32_t)out.tri_order.size();
+        uint32_t tri_off = 0, n_inner = 0;
+        for (int s = 0; s < 8; ++s) {
+            int c = slot_child[s];
+            if (c < 0) continue;
+            const Node2 &ch = b2.nodes[kids[c]];
+            for (int a = 0; a < 3; ++a) {
+                float st = step_of(nd.e[a]);
+                int lo = (int)std::floor(((double)ch.box.lo[a] - (double)nd.p[a]) / (double)st);
+                int hi = (int)std::ceil(((double)ch.box.hi[a] - (double)nd.p[a]) / (double)st);
+                lo = std::min(255, std::max(0, lo)); hi = std::min(255, std::max(0, hi));
+                // the decoded planes (fp32: p + q*step) must enclose the child box
+                while (lo > 0 && nd.p[a] + (float)lo * st > ch.box.lo[a]) --lo;
+                while (hi < 255 && nd.p[a] + (float)hi * st < ch.box.hi[a]) ++hi;
+                nd.qlo[a][s] = (uint8_t)lo; nd.qhi[a][s] = (uint8_t)hi;
+            }
+            if (ch.count == 0) {
+                nd.imask |= (uint8_t)(1u << s);
+                nd.meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
+                ++n_inner;
+            } else {
+                nd.meta[s] = (uint8_t)((((1u << ch.count) - 1u) << 5) | tri_off);
+                for (uint32_t i = 0; i < ch.count; ++i) out.tri_order.push_back(b2.order[ch.first + i]);
+                tri_off += ch.count;
+            }
+        }
+        // internal children in slot order => relative index = popcount(imask below the slot)
+        for (int s = 0; s < 8; ++s) {
+            int c = slot_child[s];
+            if (c < 0 || b2.nodes[kids[c]].count != 0) continue;
+            queue.push_back({kids[c], depth + 1});
+        }
+        out.nodes.resize(out.nodes.size() + n_inner);
+        out.nodes[qi] = nd;
+    }
+    return true;
+}
+
+}  // namespace ptx

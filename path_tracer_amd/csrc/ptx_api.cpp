@@ -1,0 +1,611 @@
+// ptx_api.cpp -- the C ABI of include/ptx.h: context, scene buffers, acceleration-structure
+// build, wavefront render loop, readback.  Mirrors the host half of the reference's hot path:
+// Renderer::new / record_commands / resize_render_buffer / readback (renderer.rs:183,583,668,906),
+// Scene::add_* (scene/mod.rs:270-520) and Geometry::create (scene/geometry/mod.rs:54-103).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/ptx.h"
+#include "bvh8.h"
+#include "ptx_context_access.h"
+#include "ptx_kernels.h"
+
+using namespace ptx;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Geometry { uint64_t first_vertex, n_vertices, first_index, n_indices; };
+
+struct EventPair { hipEvent_t a, b; int kind; };   // kind 0 extend, 1 shade, 2 whole render call
+
+}  // namespace
+
+struct ptx_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ptx_limits limits{};
+    std::string err;
+
+    // host mirrors of the reference's shared scene buffers (scene/mod.rs:48-54)
+    std::vector<ptx_vertex> vertices;
+    std::vector<uint32_t> indices;
+    std::vector<ptx_material> materials;
+    std::vector<Geometry> geometries;
+    std::vector<TexDesc> textures;          // device texel pointers
+    uint32_t n_instances = 0;
+
+    // device scene
+    Bvh8Node *d_nodes = nullptr; uint32_t n_nodes = 0;
+    TriRec *d_tris = nullptr; ShadeRec *d_shade = nullptr; uint64_t n_tris = 0;
+    ptx_material *d_materials = nullptr;
+    TexDesc *d_textures = nullptr;
+    float *d_lut = nullptr;
+    uint32_t bvh_depth = 0;
+    bool scene_ready = false;
+    bool materials_dirty = true, textures_dirty = true;
+
+    // images (renderer.rs:476-531)
+    uint32_t width = 0, height = 0;
+    float4 *d_albedo = nullptr, *d_normal = nullptr; float *d_depth = nullptr; uint2 *d_ids = nullptr;
+
+    // wavefront state
+    uint64_t path_capacity = 0;
+    uint64_t target_paths = 8u << 20;
+    RayRec *d_rays[2] = {nullptr, nullptr};
+    HitRec *d_hits = nullptr;
+    float4 *d_results = nullptr;
+    uint32_t *d_counters = nullptr;
+    uint64_t *d_totals = nullptr;           // rays, hits, samples
+
+    // profiling
+    bool profiling = false;
+    std::vector<EventPair> events;          // recorded, not yet read
+    std::vector<EventPair> event_pool;      // free
+    double extend_ms = 0, shade_ms = 0, total_ms = 0;
+    uint64_t extend_launches = 0;
+};
+
+namespace {
+
+int fail(ptx_context *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail((c), PTX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+int bind(ptx_context *c)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    return PTX_OK;
+}
+
+template <class T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+void free_paths(ptx_context *c)
+{
+    dfree(c->d_rays[0]); dfree(c->d_rays[1]); dfree(c->d_hits); dfree(c->d_results);
+    c->path_capacity = 0;
+}
+
+int ensure_paths(ptx_context *c, uint64_t n)
+{
+    if (n <= c->path_capacity) return PTX_OK;
+    free_paths(c);
+    HIP_TRY(c, hipMalloc((void **)&c->d_rays[0], n * sizeof(RayRec)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_rays[1], n * sizeof(RayRec)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_hits, n * sizeof(HitRec)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_results, n * sizeof(float4)));
+    c->path_capacity = n;
+    return PTX_OK;
+}
+
+void srgb_lut(float *lut)
+{
+    // IEC 61966-2-1 decode, as sampling an R8G8B8A8_SRGB image does (graphics.rs:494-495)
+    for (int i = 0; i < 256; ++i) {
+        double v = i / 255.0;
+        double l = (v <= 0.04045) ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4);
+        lut[i] = (float)l;
+    }
+}
+
+EventPair get_events(ptx_context *c, int kind)
+{
+    EventPair p;
+    if (!c->event_pool.empty()) { p = c->event_pool.back(); c->event_pool.pop_back(); }
+    else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
+    p.kind = kind;
+    return p;
+}
+
+void drain_events(ptx_context *c)
+{
+    for (EventPair &p : c->events) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            if (p.kind == 0) { c->extend_ms += ms; c->extend_launches++; }
+            else if (p.kind == 1) c->shade_ms += ms;
+            else c->total_ms += ms;
+        }
+        c->event_pool.push_back(p);
+    }
+    c->events.clear();
+}
+
+inline void xform_point(const float m[3][4], const float p[3], float out[3])
+{
+    for (int r = 0; r < 3; ++r) out[r] = ((m[r][0] * p[0] + m[r][1] * p[1]) + m[r][2] * p[2]) + m[r][3];
+}
+
+}  // namespace
+
+namespace ptx {
+uint64_t ctx_pixels(ptx_context *c) { return (uint64_t)c->width * c->height; }
+int ctx_device(ptx_context *c) { return c->device; }
+void *ctx_albedo(ptx_context *c) { return c->d_albedo; }
+hipStream_t ctx_stream(ptx_context *c) { return c->stream; }
+int ctx_fail(ptx_context *c, int code, const std::string &msg) { return fail(c, code, msg); }
+}  // namespace ptx
+
+extern "C" {
+
+void ptx_default_limits(ptx_limits *l)
+{
+    l->max_vertices = 2500000; l->max_indices = 5000000; l->max_materials = 10000; l->max_offsets = 10000;
+    l->max_textures = 5000; l->_pad = 0;
+}
+
+void ptx_default_params(ptx_render_params *p)
+{
+    memset(p, 0, sizeof *p);
+    p->max_depth = 16; p->t_min = 0.001f; p->t_max = 10000.0f; p->normal_eps = 0.001f;
+}
+
+int ptx_create_with_limits(int device_ordinal, const ptx_limits *limits, ptx_context **out)
+{
+    if (!out) return fail(nullptr, PTX_ERR_INVALID, "ptx_create: ctx is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, PTX_ERR_HIP, std::string("ptx_create: no HIP device (") + hipGetErrorString(e) + ")");
+    if (device_ordinal < 0 || device_ordinal >= n)
+        return fail(nullptr, PTX_ERR_INVALID, "ptx_create: device ordinal out of range");
+    ptx_context *c = new (std::nothrow) ptx_context;
+    if (!c) return fail(nullptr, PTX_ERR_INVALID, "ptx_create: out of host memory");
+    c->device = device_ordinal;
+    if (limits) c->limits = *limits; else ptx_default_limits(&c->limits);
+    if (const char *tp = getenv("PTX_TARGET_PATHS")) {
+        unsigned long long v = strtoull(tp, nullptr, 10);
+        if (v >= 4096) c->target_paths = v;
+    }
+#define CREATE_TRY(expr)                                                                            \
+    do {                                                                                            \
+        hipError_t e2_ = (expr);                                                                    \
+        if (e2_ != hipSuccess) {                                                                    \
+            fail(nullptr, PTX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e2_));         \
+            ptx_destroy(c);                                                                         \
+            return PTX_ERR_HIP;                                                                     \
+        }                                                                                           \
+    } while (0)
+    CREATE_TRY(hipSetDevice(device_ordinal));
+    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipMalloc((void **)&c->d_counters, kNumCounters * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc((void **)&c->d_totals, 3 * sizeof(uint64_t)));
+    CREATE_TRY(hipMemset(c->d_totals, 0, 3 * sizeof(uint64_t)));
+    CREATE_TRY(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
+    float lut[256]; srgb_lut(lut);
+    CREATE_TRY(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+#undef CREATE_TRY
+    *out = c;
+    return PTX_OK;
+}
+
+int ptx_create(int device_ordinal, ptx_context **out) { return ptx_create_with_limits(device_ordinal, nullptr, out); }
+
+int ptx_destroy(ptx_context *c)
+{
+    if (!c) return PTX_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drain_events(c);
+    for (EventPair &p : c->event_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (TexDesc &t : c->textures) { void *p = (void *)t.texels; if (p) (void)hipFree(p); }
+    dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_materials); dfree(c->d_textures); dfree(c->d_lut);
+    dfree(c->d_albedo); dfree(c->d_normal); dfree(c->d_depth); dfree(c->d_ids);
+    free_paths(c);
+    dfree(c->d_counters); dfree(c->d_totals);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PTX_OK;
+}
+
+const char *ptx_last_error(ptx_context *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int ptx_add_vertices(ptx_context *c, const ptx_vertex *v, uint64_t n, uint64_t *first)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if ((!v && n) || !first) return fail(c, PTX_ERR_INVALID, "ptx_add_vertices: NULL argument");
+    if (c->vertices.size() + n > c->limits.max_vertices)
+        return fail(c, PTX_ERR_CAPACITY, "ptx_add_vertices: vertex buffer overflow");   // scene/mod.rs:281-283
+    *first = c->vertices.size();
+    c->vertices.insert(c->vertices.end(), v, v + n);
+    return PTX_OK;
+}
+
+int ptx_add_indices(ptx_context *c, const uint32_t *idx, uint64_t n, uint64_t *first)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if ((!idx && n) || !first) return fail(c, PTX_ERR_INVALID, "ptx_add_indices: NULL argument");
+    if (c->indices.size() + n > c->limits.max_indices)
+        return fail(c, PTX_ERR_CAPACITY, "ptx_add_indices: index buffer overflow");     // scene/mod.rs:412-414
+    *first = c->indices.size();
+    c->indices.insert(c->indices.end(), idx, idx + n);
+    return PTX_OK;
+}
+
+int ptx_add_material(ptx_context *c, const ptx_material *m, uint32_t *index)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (!m || !index) return fail(c, PTX_ERR_INVALID, "ptx_add_material: NULL argument");
+    if (c->materials.size() + 1 > c->limits.max_materials)
+        return fail(c, PTX_ERR_CAPACITY, "ptx_add_material: material buffer overflow"); // scene/mod.rs:347-349
+    *index = (uint32_t)c->materials.size();
+    c->materials.push_back(*m);
+    c->materials_dirty = true;
+    return PTX_OK;
+}
+
+int ptx_add_texture(ptx_context *c, const uint8_t *rgba8, uint32_t w, uint32_t h, int srgb, uint32_t *index)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (!rgba8 || !index || w == 0 || h == 0) return fail(c, PTX_ERR_INVALID, "ptx_add_texture: bad argument");
+    if (c->textures.size() + 1 > c->limits.max_textures)
+        return fail(c, PTX_ERR_CAPACITY, "ptx_add_texture: bindless texture pool size exceeded"); // renderer.rs:899-901
+    if (int r = bind(c)) return r;
+    void *d = nullptr;
+    uint64_t bytes = (uint64_t)w * h * 4;
+    HIP_TRY(c, hipMalloc(&d, bytes));
+    hipError_t e = hipMemcpy(d, rgba8, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return fail(c, PTX_ERR_HIP, std::string("ptx_add_texture: ") + hipGetErrorString(e)); }
+    TexDesc t; t.texels = (const uint8_t *)d; t.width = w; t.height = h; t.srgb = srgb ? 1u : 0u; t._pad = 0;
+    *index = (uint32_t)c->textures.size();
+    c->textures.push_back(t);
+    c->textures_dirty = true;
+    return PTX_OK;
+}
+
+int ptx_create_geometry(ptx_context *c, uint64_t first_vertex, uint64_t n_vertices, uint64_t first_index,
+                        uint64_t n_indices, uint32_t *geometry)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (!geometry) return fail(c, PTX_ERR_INVALID, "ptx_create_geometry: NULL argument");
+    if (first_vertex + n_vertices > c->vertices.size() || first_index + n_indices > c->indices.size())
+        return fail(c, PTX_ERR_INVALID, "ptx_create_geometry: range outside the shared buffers");
+    if (n_indices % 3 != 0) return fail(c, PTX_ERR_INVALID, "ptx_create_geometry: index count is not a multiple of 3");
+    for (uint64_t i = 0; i < n_indices; ++i)
+        if (c->indices[first_index + i] >= n_vertices)
+            return fail(c, PTX_ERR_INVALID, "ptx_create_geometry: index refers past the geometry's vertices");
+    *geometry = (uint32_t)c->geometries.size();
+    c->geometries.push_back({first_vertex, n_vertices, first_index, n_indices});
+    return PTX_OK;
+}
+
+int ptx_set_instances(ptx_context *c, const ptx_instance *inst, uint32_t n)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (!inst && n) return fail(c, PTX_ERR_INVALID, "ptx_set_instances: NULL argument");
+    if (n > c->limits.max_offsets) return fail(c, PTX_ERR_CAPACITY, "ptx_set_instances: offsets buffer overflow");
+    if (int r = bind(c)) return r;
+
+    uint64_t n_tris = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const ptx_instance &in = inst[i];
+        if (in.geometry >= c->geometries.size())
+            return fail(c, PTX_ERR_INVALID, "ptx_set_instances: unknown geometry handle");
+        const Geometry &g = c->geometries[in.geometry];
+        // the Offsets row must address the geometry the instance names (renderer.rs:927-939)
+        if (in.off.vertex_offset != g.first_vertex || in.off.index_offset != g.first_index ||
+            in.off.index_count != g.n_indices || in.off.vertex_count != g.n_vertices)
+            return fail(c, PTX_ERR_INVALID, "ptx_set_instances: offsets row does not match its geometry");
+        if (in.off.material_offset >= c->materials.size())
+            return fail(c, PTX_ERR_INVALID, "ptx_set_instances: material offset out of range");
+        const ptx_material &m = c->materials[in.off.material_offset];
+        if (m.has_base_texture && m.base_texture_indice >= c->textures.size())
+            return fail(c, PTX_ERR_INVALID, "ptx_set_instances: material refers to a texture that was never added");
+        n_tris += g.n_indices / 3;
+    }
+
+    // flatten to world space: the instance transform is applied once here instead of per ray
+    std::vector<float> wv(n_tris * 9);
+    std::vector<uint32_t> tri_inst(n_tris), tri_prim(n_tris);
+    {
+        uint64_t k = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const ptx_instance &in = inst[i];
+            const Geometry &g = c->geometries[in.geometry];
+            uint64_t np = g.n_indices / 3;
+            for (uint64_t p = 0; p < np; ++p, ++k) {
+                for (int v = 0; v < 3; ++v) {
+                    const ptx_vertex &vx = c->vertices[g.first_vertex + c->indices[g.first_index + p * 3 + v]];
+                    xform_point(in.xform, vx.position, &wv[k * 9 + v * 3]);
+                }
+                tri_inst[k] = i; tri_prim[k] = (uint32_t)p;
+            }
+        }
+    }
+    Bvh8 bvh;
+    int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (!build_bvh8(wv.data(), n_tris, bvh, threads)) return fail(c, PTX_ERR_INVALID, "ptx_set_instances: BVH build failed");
+    if (bvh.depth > kMaxBvhDepth) return fail(c, PTX_ERR_CAPACITY, "ptx_set_instances: BVH deeper than the traversal stack");
+
+    uint64_t nt = bvh.tri_order.size();
+    std::vector<TriRec> tris(nt);
+    std::vector<ShadeRec> shade(nt);
+    for (uint64_t k = 0; k < nt; ++k) {
+        uint32_t t = bvh.tri_order[k];
+        const ptx_instance &in = inst[tri_inst[t]];
+        const Geometry &g = c->geometries[in.geometry];
+        const uint32_t *ix = &c->indices[g.first_index + (uint64_t)tri_prim[t] * 3];
+        const ptx_vertex &a = c->vertices[g.first_vertex + ix[0]];
+        const ptx_vertex &b = c->vertices[g.first_vertex + ix[1]];
+        const ptx_vertex &d = c->vertices[g.first_vertex + ix[2]];
+        TriRec &tr = tris[k];
+        memcpy(tr.v0, &wv[(uint64_t)t * 9], 12); memcpy(tr.v1, &wv[(uint64_t)t * 9 + 3], 12); memcpy(tr.v2, &wv[(uint64_t)t * 9 + 6], 12);
+        tr.instance = tri_inst[t]; tr.prim = tri_prim[t]; tr.material = in.off.material_offset;
+        ShadeRec &sr = shade[k];
+        memcpy(sr.n0, a.normal, 12); memcpy(sr.n1, b.normal, 12); memcpy(sr.n2, d.normal, 12);   // object space, as the reference
+        memcpy(sr.uv0, a.uv, 8); memcpy(sr.uv1, b.uv, 8); memcpy(sr.uv2, d.uv, 8);
+        sr.material = in.off.material_offset;
+    }
+
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade);
+    c->scene_ready = false;
+    c->n_nodes = (uint32_t)bvh.nodes.size(); c->n_tris = nt; c->bvh_depth = bvh.depth;
+    if (c->n_nodes) {
+        HIP_TRY(c, hipMalloc((void **)&c->d_nodes, bvh.nodes.size() * sizeof(Bvh8Node)));
+        HIP_TRY(c, hipMemcpy(c->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(Bvh8Node), hipMemcpyHostToDevice));
+    }
+    if (nt) {
+        HIP_TRY(c, hipMalloc((void **)&c->d_tris, nt * sizeof(TriRec)));
+        HIP_TRY(c, hipMemcpy(c->d_tris, tris.data(), nt * sizeof(TriRec), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMalloc((void **)&c->d_shade, nt * sizeof(ShadeRec)));
+        HIP_TRY(c, hipMemcpy(c->d_shade, shade.data(), nt * sizeof(ShadeRec), hipMemcpyHostToDevice));
+    }
+    if (c->materials_dirty) {
+        dfree(c->d_materials);
+        if (!c->materials.empty()) {
+            HIP_TRY(c, hipMalloc((void **)&c->d_materials, c->materials.size() * sizeof(ptx_material)));
+            HIP_TRY(c, hipMemcpy(c->d_materials, c->materials.data(), c->materials.size() * sizeof(ptx_material), hipMemcpyHostToDevice));
+        }
+        c->materials_dirty = false;
+    }
+    if (c->textures_dirty) {
+        dfree(c->d_textures);
+        if (!c->textures.empty()) {
+            HIP_TRY(c, hipMalloc((void **)&c->d_textures, c->textures.size() * sizeof(TexDesc)));
+            HIP_TRY(c, hipMemcpy(c->d_textures, c->textures.data(), c->textures.size() * sizeof(TexDesc), hipMemcpyHostToDevice));
+        }
+        c->textures_dirty = false;
+    }
+    c->n_instances = n;
+    c->scene_ready = true;
+    return PTX_OK;
+}
+
+int ptx_resize(ptx_context *c, uint32_t w, uint32_t h)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (w == 0 || h == 0 || (uint64_t)w * h > 0x40000000ull) return fail(c, PTX_ERR_INVALID, "ptx_resize: bad extent");
+    if (int r = bind(c)) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    dfree(c->d_albedo); dfree(c->d_normal); dfree(c->d_depth); dfree(c->d_ids);
+    c->width = c->height = 0;
+    uint64_t np = (uint64_t)w * h;
+    HIP_TRY(c, hipMalloc((void **)&c->d_albedo, np * 16));
+    HIP_TRY(c, hipMalloc((void **)&c->d_normal, np * 16));
+    HIP_TRY(c, hipMalloc((void **)&c->d_depth, np * 4));
+    HIP_TRY(c, hipMalloc((void **)&c->d_ids, np * 8));
+    HIP_TRY(c, hipMemset(c->d_albedo, 0, np * 16));
+    HIP_TRY(c, hipMemset(c->d_normal, 0, np * 16));
+    HIP_TRY(c, hipMemset(c->d_depth, 0, np * 4));
+    HIP_TRY(c, hipMemset(c->d_ids, 0xFF, np * 8));
+    c->width = w; c->height = h;
+    return PTX_OK;
+}
+
+int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *cam, const ptx_render_params *pp,
+                     uint32_t n_samples)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (!u || !cam) return fail(c, PTX_ERR_INVALID, "ptx_render: NULL argument");
+    if (!c->scene_ready) return fail(c, PTX_ERR_STATE, "ptx_render: ptx_set_instances has not been called");
+    if (!c->width) return fail(c, PTX_ERR_STATE, "ptx_render: ptx_resize has not been called");
+    ptx_render_params p;
+    if (pp) p = *pp; else ptx_default_params(&p);
+    if (p.max_depth > kMaxDepthLimit) return fail(c, PTX_ERR_INVALID, "ptx_render: max_depth above 64");
+    if (n_samples == 0) return PTX_OK;
+    if (int r = bind(c)) return r;
+
+    const uint64_t npix = (uint64_t)c->width * c->height;
+    uint64_t chunk = std::max<uint64_t>(1, c->target_paths / npix);
+    chunk = std::min<uint64_t>(chunk, n_samples);
+    if (chunk * npix > 0xFFFFFF00ull) chunk = 0xFFFFFF00ull / npix;
+    if (int r = ensure_paths(c, chunk * npix)) return r;
+
+    SceneDev sc;
+    sc.nodes = c->d_nodes; sc.n_nodes = c->n_nodes; sc.tris = c->d_tris; sc.shade = c->d_shade;
+    sc.materials = c->d_materials; sc.textures = c->d_textures; sc.srgb_lut = c->d_lut;
+    ImagesDev img; img.albedo = c->d_albedo; img.normal = c->d_normal; img.depth = c->d_depth; img.ids = c->d_ids;
+    FrameDev f;
+    f.cam = *cam;
+    f.width = c->width; f.height = c->height; f.n_pixels = (uint32_t)npix;
+    f.seed = u->seed; f.rng_offset = p.rng_sample_offset;
+    f.max_depth = p.max_depth; f.t_min = p.t_min; f.t_max = p.t_max; f.normal_eps = p.normal_eps;
+    f.z_near = u->z_near; f.z_far = u->z_far;
+    const uint32_t bounces = std::max(1u, p.max_depth);
+
+    EventPair whole{};
+    if (c->profiling) { whole = get_events(c, 2); HIP_TRY(c, hipEventRecord(whole.a, c->stream)); }
+    for (uint32_t s0 = 0; s0 < n_samples; s0 += (uint32_t)chunk) {
+        uint32_t ns = (uint32_t)std::min<uint64_t>(chunk, n_samples - s0);
+        uint32_t n_paths = (uint32_t)(ns * npix);
+        f.mean_base = u->accumulated_count + s0;
+        f.ids_sample = (s0 == 0) ? 0u : 0xFFFFFFFFu;
+        launch_raygen(c->stream, f, n_paths, c->d_rays[0], c->d_counters);
+        for (uint32_t b = 0; b < bounces; ++b) {
+            RayRec *rin = c->d_rays[b & 1], *rout = c->d_rays[(b & 1) ^ 1];
+            if (c->profiling) {
+                EventPair e = get_events(c, 0);
+                HIP_TRY(c, hipEventRecord(e.a, c->stream));
+                launch_extend(c->stream, sc, f, rin, c->d_counters + b, n_paths, c->d_hits);
+                HIP_TRY(c, hipEventRecord(e.b, c->stream));
+                c->events.push_back(e);
+                EventPair e2 = get_events(c, 1);
+                HIP_TRY(c, hipEventRecord(e2.a, c->stream));
+                launch_shade(c->stream, sc, f, img, b, rin, c->d_hits, c->d_counters, n_paths, rout, c->d_results);
+                HIP_TRY(c, hipEventRecord(e2.b, c->stream));
+                c->events.push_back(e2);
+            } else {
+                launch_extend(c->stream, sc, f, rin, c->d_counters + b, n_paths, c->d_hits);
+                launch_shade(c->stream, sc, f, img, b, rin, c->d_hits, c->d_counters, n_paths, rout, c->d_results);
+            }
+        }
+        launch_resolve(c->stream, f, img, c->d_results, ns);
+        launch_accumulate_stats(c->stream, c->d_counters, bounces, (uint64_t)n_paths, c->d_totals);
+    }
+    if (c->profiling) { HIP_TRY(c, hipEventRecord(whole.b, c->stream)); c->events.push_back(whole); }
+    HIP_TRY(c, hipGetLastError());
+    return PTX_OK;
+}
+
+int ptx_render(ptx_context *c, const ptx_uniforms *u, const ptx_camera *cam, const ptx_render_params *p)
+{
+    return ptx_render_batch(c, u, cam, p, 1);
+}
+
+int ptx_read_image(ptx_context *c, int kind, void *dst, uint64_t bytes)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (!dst) return fail(c, PTX_ERR_INVALID, "ptx_read_image: NULL destination");
+    if (!c->width) return fail(c, PTX_ERR_STATE, "ptx_read_image: no image (ptx_resize not called)");
+    uint64_t np = (uint64_t)c->width * c->height;
+    const void *src = nullptr; uint64_t want = 0;
+    switch (kind) {
+    case PTX_IMAGE_ALBEDO: src = c->d_albedo; want = np * 16; break;
+    case PTX_IMAGE_NORMAL: src = c->d_normal; want = np * 16; break;
+    case PTX_IMAGE_DEPTH: src = c->d_depth; want = np * 4; break;
+    case PTX_IMAGE_PRIMARY_ID: src = c->d_ids; want = np * 8; break;
+    default: return fail(c, PTX_ERR_INVALID, "ptx_read_image: unknown image kind");
+    }
+    if (bytes != want) return fail(c, PTX_ERR_INVALID, "ptx_read_image: byte count does not match the image");
+    if (int r = bind(c)) return r;
+    HIP_TRY(c, hipMemcpyAsync(dst, src, want, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PTX_OK;
+}
+
+int ptx_write_albedo(ptx_context *c, const void *src, uint64_t bytes)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (!src) return fail(c, PTX_ERR_INVALID, "ptx_write_albedo: NULL source");
+    if (!c->width) return fail(c, PTX_ERR_STATE, "ptx_write_albedo: no image");
+    if (bytes != (uint64_t)c->width * c->height * 16) return fail(c, PTX_ERR_INVALID, "ptx_write_albedo: byte count does not match the image");
+    if (int r = bind(c)) return r;
+    HIP_TRY(c, hipMemcpyAsync(c->d_albedo, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PTX_OK;
+}
+
+int ptx_export_albedo_device(ptx_context *c, void *device_dst, uint64_t bytes, float scale)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (!device_dst) return fail(c, PTX_ERR_INVALID, "ptx_export_albedo_device: NULL destination");
+    if (!c->width) return fail(c, PTX_ERR_STATE, "ptx_export_albedo_device: no image");
+    uint64_t np = (uint64_t)c->width * c->height;
+    if (bytes != np * 16) return fail(c, PTX_ERR_INVALID, "ptx_export_albedo_device: byte count does not match the image");
+    if (int r = bind(c)) return r;
+    launch_scale_copy(c->stream, c->d_albedo, (float4 *)device_dst, np, scale);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PTX_OK;
+}
+
+int ptx_import_albedo_device(ptx_context *c, const void *device_src, uint64_t bytes, float scale)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (!device_src) return fail(c, PTX_ERR_INVALID, "ptx_import_albedo_device: NULL source");
+    if (!c->width) return fail(c, PTX_ERR_STATE, "ptx_import_albedo_device: no image");
+    uint64_t np = (uint64_t)c->width * c->height;
+    if (bytes != np * 16) return fail(c, PTX_ERR_INVALID, "ptx_import_albedo_device: byte count does not match the image");
+    if (int r = bind(c)) return r;
+    launch_scale_copy(c->stream, (const float4 *)device_src, c->d_albedo, np, scale);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PTX_OK;
+}
+
+int ptx_synchronize(ptx_context *c)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PTX_OK;
+}
+
+int ptx_set_profiling(ptx_context *c, int enabled)
+{
+    if (!c) return PTX_ERR_INVALID;
+    c->profiling = enabled != 0;
+    return PTX_OK;
+}
+
+int ptx_get_stats(ptx_context *c, ptx_stats *s)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (!s) return fail(c, PTX_ERR_INVALID, "ptx_get_stats: NULL argument");
+    if (int r = bind(c)) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drain_events(c);
+    uint64_t t[3];
+    HIP_TRY(c, hipMemcpy(t, c->d_totals, sizeof t, hipMemcpyDeviceToHost));
+    memset(s, 0, sizeof *s);
+    s->rays = t[0]; s->hits = t[1]; s->samples = t[2];
+    s->extend_launches = c->extend_launches; s->extend_ms = c->extend_ms; s->shade_ms = c->shade_ms; s->total_ms = c->total_ms;
+    s->bvh_nodes = c->n_nodes; s->bvh_triangles = c->n_tris;
+    s->bvh_bytes = (uint64_t)c->n_nodes * sizeof(Bvh8Node) + c->n_tris * (sizeof(TriRec) + sizeof(ShadeRec));
+    s->bvh_depth = c->bvh_depth;
+    return PTX_OK;
+}
+
+int ptx_reset_stats(ptx_context *c)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drain_events(c);
+    HIP_TRY(c, hipMemset(c->d_totals, 0, 3 * sizeof(uint64_t)));
+    c->extend_ms = c->shade_ms = c->total_ms = 0; c->extend_launches = 0;
+    return PTX_OK;
+}
+
+}  // extern "C"

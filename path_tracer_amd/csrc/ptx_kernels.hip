@@ -1,0 +1,317 @@
+// ptx_kernels.hip -- gfx950 wavefront path-tracing stages.  Hand-written HIP for CDNA4
+// (wave64); no CUDA shims, no dual paths.
+//
+//   raygen   rgen.glsl:20-60     camera ray per (sample, pixel) path
+//   extend   rgen.glsl:66-78     closest hit = software traversal of the compressed 8-wide BVH
+//   shade    rchit.glsl:158-254 / rmiss.glsl:18-34 + rgen.glsl:80-107: scatter or terminate,
+//            G-buffers, wave64 ballot + mbcnt compaction of the surviving rays
+//   resolve  rgen.glsl:124-141   running-mean accumulation, samples applied in order
+//
+// All paths of a chunk advance bounce by bounce (one extend + one shade launch per bounce), so
+// `depth` is uniform per launch and every pixel receives its samples in accumulated_count
+// order -- the image is bit-identical to the reference's frame-by-frame loop.
+#include <hip/hip_runtime.h>
+
+#include "ptx_kernels.h"
+
+namespace ptx {
+
+namespace {
+
+constexpr int kExtendBlock = 64;    // one wave per workgroup: resources free as soon as the wave retires
+constexpr int kShadeBlock = 256;
+
+__device__ __forceinline__ f3 mat4_mul(const float *m, float x, float y, float z, float w)
+{
+    // GLSL mat4 * vec4 = c0*x + c1*y + c2*z + c3*w, summed left to right
+    f3 r;
+    r.x = ((m[0] * x + m[4] * y) + m[8] * z) + m[12] * w;
+    r.y = ((m[1] * x + m[5] * y) + m[9] * z) + m[13] * w;
+    r.z = ((m[2] * x + m[6] * y) + m[10] * z) + m[14] * w;
+    return r;
+}
+
+// ---------------------------------------------------------------- raygen
+__global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, RayRec *__restrict__ rays,
+                                                uint32_t *__restrict__ counters)
+{
+    uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p == 0) {
+        counters[0] = n_paths;
+        for (uint32_t i = 1; i < kNumCounters; ++i) counters[i] = 0;
+    }
+    if (p >= n_paths) return;
+    uint32_t pix = p % f.n_pixels;
+    uint32_t y = pix / f.width, x = pix - y * f.width;
+    // rgen.glsl:25-28
+    float pcx = (float)x + 0.5f, pcy = (float)(f.height - y - 1u) + 0.5f;
+    float uvx = pcx / (float)f.width, uvy = pcy / (float)f.height;
+    float dx = uvx * 2.0f - 1.0f, dy = uvy * 2.0f - 1.0f;
+    // rgen.glsl:30-34
+    f3 origin = mat4_mul(f.cam.view_inverse, 0.0f, 0.0f, 0.0f, 1.0f);
+    f3 target = mat4_mul(f.cam.proj_inverse, dx, dy, 1.0f, 1.0f);
+    f3 tn = normalize(target);
+    f3 dir = normalize(mat4_mul(f.cam.view_inverse, tn.x, tn.y, tn.z, 0.0f));
+
+    float4 *out = reinterpret_cast<float4 *>(rays + p);
+    out[0] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(p));
+    out[1] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(hash2(f2u(uvx), f2u(uvy))));
+    out[2] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);   // rgen.glsl:62
+}
+
+// ---------------------------------------------------------------- extend
+struct LaneStack {
+    uint2 *lds;                 // this lane's column of the workgroup's LDS stack
+    uint2 ovf[kOvfStack];
+    int sp;
+    __device__ __forceinline__ void push(uint32_t base, uint32_t mask)
+    {
+        if (sp < kLdsStack) lds[sp * kExtendBlock] = make_uint2(base, mask);
+        else ovf[sp - kLdsStack] = make_uint2(base, mask);
+        ++sp;
+    }
+    __device__ __forceinline__ void pop(uint32_t &base, uint32_t &mask)
+    {
+        --sp;
+        uint2 v = (sp < kLdsStack) ? lds[sp * kExtendBlock] : ovf[sp - kLdsStack];
+        base = v.x; mask = v.y;
+    }
+    __device__ __forceinline__ bool empty() const { return sp == 0; }
+};
+
+__global__ void __launch_bounds__(kExtendBlock) k_extend(SceneDev sc, float t_min, float t_max,
+                                                          const RayRec *__restrict__ rays,
+                                                          const uint32_t *__restrict__ count,
+                                                          HitRec *__restrict__ hits)
+{
+    __shared__ uint2 s_stack[kLdsStack * kExtendBlock];
+    uint32_t i = blockIdx.x * kExtendBlock + threadIdx.x;
+    if (i >= *count) return;
+    const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
+    float4 r0 = rp[0], r1 = rp[1];
+    LaneStack st;
+    st.lds = s_stack + threadIdx.x;
+    st.sp = 0;
+    HitRec h;
+    traverse_closest<LaneStack, false>(sc.nodes, sc.n_nodes, sc.tris, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z),
+                                       t_min, t_max, st, h, nullptr);
+    *reinterpret_cast<float4 *>(hits + i) = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+}
+
+// ---------------------------------------------------------------- shade
+__device__ __forceinline__ f3 sample_texture(const TexDesc &tx, const float *lut, float u, float v)
+{
+    // vulkano SamplerCreateInfo::default(): nearest, clamp-to-edge, LOD 0 (graphics.rs:453-459)
+    float fu = floorf(u * (float)tx.width), fv = floorf(v * (float)tx.height);
+    float mu = (float)(tx.width - 1u), mv = (float)(tx.height - 1u);
+    if (!(fu >= 0.0f)) fu = 0.0f;
+    if (fu > mu) fu = mu;
+    if (!(fv >= 0.0f)) fv = 0.0f;
+    if (fv > mv) fv = mv;
+    uint32_t texel = *reinterpret_cast<const uint32_t *>(tx.texels + ((uint64_t)(uint32_t)fv * tx.width + (uint32_t)fu) * 4u);
+    uint32_t r = texel & 0xFFu, g = (texel >> 8) & 0xFFu, b = (texel >> 16) & 0xFFu;
+    if (tx.srgb) return mk3(lut[r], lut[g], lut[b]);
+    return mk3((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f);
+}
+
+__global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, ImagesDev img, uint32_t depth,
+                                                        const RayRec *__restrict__ rays_in,
+                                                        const HitRec *__restrict__ hits,
+                                                        uint32_t *__restrict__ counters,
+                                                        RayRec *__restrict__ rays_out, float4 *__restrict__ results)
+{
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];
+    __syncthreads();
+
+    uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x;
+    bool valid = i < counters[depth];
+    bool alive = false, was_hit = false;
+    float4 o0, o1, o2;
+    if (valid) {
+        const float4 *rp = reinterpret_cast<const float4 *>(rays_in + i);
+        float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+        float4 hr = *reinterpret_cast<const float4 *>(hits + i);
+        f3 ro = mk3(r0.x, r0.y, r0.z), rd = mk3(r1.x, r1.y, r1.z);
+        uint32_t path = __float_as_uint(r0.w), uv_state = __float_as_uint(r1.w);
+        uint32_t sample = path / f.n_pixels, pix = path - sample * f.n_pixels;
+        uint32_t acc = f.mean_base + sample;            // uniforms.accumulated_count of this path's frame
+        uint32_t tri = __float_as_uint(hr.w);
+
+        f3 att, normal, new_o = ro, new_d = rd;
+        float dist;
+        int done;
+        uint32_t id_inst = 0xFFFFFFFFu, id_prim = 0xFFFFFFFFu;
+        if (tri == 0xFFFFFFFFu) {
+            // rmiss.glsl:18-34
+            att = sky_color(rd);
+            done = 1;
+            dist = 3.402823466e+38f;
+            normal = mk3(0.0f, 0.0f, 0.0f);
+        } else {
+            was_hit = true;
+            // rchit.glsl:160-183
+            const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri);
+            float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+            f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
+            float bx = 1.0f - hr.y - hr.z, by = hr.y, bz = hr.z;
+            normal = normalize((n0 * bx + n1 * by) + n2 * bz);
+            float tu = (s2.y * bx + s2.w * by) + s3.y * bz;
+            float tv = (s2.z * bx + s3.x * by) + s3.z * bz;
+            f3 world_pos = ro + rd * hr.x;                                   // :186
+            uint32_t mi = __float_as_uint(s3.w);
+            const float4 *mp = reinterpret_cast<const float4 *>(sc.materials + mi);
+            float4 m0 = mp[0], m1 = mp[1];                                   // :190
+            f3 albedo;
+            if (__float_as_uint(m1.x)) {                                     // :193-198
+                albedo = sample_texture(sc.textures[__float_as_uint(m1.y)], s_lut, tu, tv);
+            } else {
+                albedo = mk3(m0.x, m0.y, m0.z);
+            }
+            float roughness = m1.w;                                          // :200
+            float k2 = 2.0f * dot(normal, rd);                               // :209 reflect()
+            f3 reflected = rd - normal * k2;
+            f3 rr = normalize(cosine_hemisphere_sample(uv_state, depth, acc + f.rng_offset, f.seed, normal));
+            float om = 1.0f - roughness;                                     // :220 mix(), unnormalised
+            f3 scatter = reflected * om + rr * roughness;
+            if (dot(scatter, normal) <= 0.0f) {                              // :223-230
+                done = 1;
+                att = mk3(0.0f, 0.0f, 0.0f);
+            } else {
+                done = 0;
+                att = albedo;
+            }
+            new_o = world_pos + normal * f.normal_eps;                       // :242
+            new_d = scatter;
+            dist = length(new_o - ro);                                       // :254
+            if (depth == 0 && sample == f.ids_sample) {
+                const uint32_t *tw = reinterpret_cast<const uint32_t *>(sc.tris + tri);
+                id_inst = tw[3]; id_prim = tw[7];
+            }
+        }
+        f3 thr = mk3(r2.x, r2.y, r2.z) * att;                                // rgen.glsl:80
+
+        if (depth == 0) {                                                    // rgen.glsl:83-99
+            if (sample == f.ids_sample) img.ids[pix] = make_uint2(id_inst, id_prim);
+            if (acc == 0) {
+                float z_range = f.z_far - f.z_near;
+                float zn = (dist - f.z_near) / z_range;
+                zn = fminf(fmaxf(zn, 0.0f), 1.0f);
+                img.depth[pix] = zn;
+                img.normal[pix] = make_float4(normal.x, normal.y, normal.z, 1.0f);
+            }
+        }
+        // rgen.glsl:101-103
+        if (done == 1 || depth + 1u >= f.max_depth) {
+            results[path] = make_float4(thr.x, thr.y, thr.z, 1.0f);
+        } else {
+            alive = true;
+            o0 = make_float4(new_o.x, new_o.y, new_o.z, r0.w);
+            o1 = make_float4(new_d.x, new_d.y, new_d.z, r1.w);
+            o2 = make_float4(thr.x, thr.y, thr.z, 0.0f);
+        }
+    }
+
+    // wave64 compaction: one atomic per wave reserves a contiguous run of the next queue
+    unsigned long long live = __ballot(alive);
+    unsigned long long hitm = __ballot(was_hit);
+    uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0) {
+        if (live) base = atomicAdd(&counters[depth + 1u], (uint32_t)__popcll(live));
+        if (hitm) atomicAdd(&counters[kHitCounter], (uint32_t)__popcll(hitm));
+    }
+    base = __shfl(base, 0, 64);
+    if (alive) {
+        uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+        float4 *op = reinterpret_cast<float4 *>(rays_out + slot);
+        op[0] = o0; op[1] = o1; op[2] = o2;
+    }
+}
+
+// ---------------------------------------------------------------- resolve
+__global__ void __launch_bounds__(256) k_resolve(FrameDev f, ImagesDev img, const float4 *__restrict__ results,
+                                                 uint32_t n_samples)
+{
+    uint32_t pix = blockIdx.x * 256u + threadIdx.x;
+    if (pix >= f.n_pixels) return;
+    float4 cur = img.albedo[pix];
+    f3 c = mk3(cur.x, cur.y, cur.z);
+    for (uint32_t s = 0; s < n_samples; ++s) {
+        // rgen.glsl:124-139
+        float4 a = results[(uint64_t)s * f.n_pixels + pix];
+        float n = (float)(f.mean_base + s);
+        f3 scaled_cur = mk3(c.x * n / (n + 1.0f), c.y * n / (n + 1.0f), c.z * n / (n + 1.0f));
+        f3 scaled_att = mk3(a.x / (n + 1.0f), a.y / (n + 1.0f), a.z / (n + 1.0f));
+        c = scaled_att + scaled_cur;
+    }
+    img.albedo[pix] = make_float4(c.x, c.y, c.z, 1.0f);                      // :141
+}
+
+__global__ void k_accumulate_stats(const uint32_t *__restrict__ counters, uint32_t max_depth, uint64_t n_samples,
+                                   uint64_t *__restrict__ totals)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint64_t rays = 0;
+        for (uint32_t b = 0; b < max_depth; ++b) rays += counters[b];
+        totals[0] += rays;
+        totals[1] += counters[kHitCounter];
+        totals[2] += n_samples;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_scale_copy(const float4 *src, float4 *dst, uint64_t n, float scale)   // src may equal dst
+{
+    uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float4 v = src[i];
+    dst[i] = make_float4(v.x * scale, v.y * scale, v.z * scale, 1.0f);
+}
+
+}  // namespace
+
+void launch_raygen(hipStream_t s, const FrameDev &f, uint32_t n_paths, RayRec *rays, uint32_t *counters)
+{
+    uint32_t blocks = (n_paths + 255u) / 256u;
+    hipLaunchKernelGGL(k_raygen, dim3(blocks ? blocks : 1u), dim3(256), 0, s, f, n_paths, rays, counters);
+}
+
+void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, const RayRec *rays, const uint32_t *count,
+                   uint32_t capacity, HitRec *hits)
+{
+    uint32_t blocks = (capacity + kExtendBlock - 1u) / kExtendBlock;
+    if (!blocks) return;
+    hipLaunchKernelGGL(k_extend, dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, hits);
+}
+
+void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
+                  const RayRec *rays_in, const HitRec *hits, uint32_t *counters, uint32_t capacity, RayRec *rays_out,
+                  float4 *results)
+{
+    uint32_t blocks = (capacity + kShadeBlock - 1u) / kShadeBlock;
+    if (!blocks) return;
+    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kShadeBlock), 0, s, sc, f, img, depth, rays_in, hits, counters,
+                       rays_out, results);
+}
+
+void launch_resolve(hipStream_t s, const FrameDev &f, const ImagesDev &img, const float4 *results, uint32_t n_samples)
+{
+    uint32_t blocks = (f.n_pixels + 255u) / 256u;
+    if (!blocks) return;
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, s, f, img, results, n_samples);
+}
+
+void launch_accumulate_stats(hipStream_t s, const uint32_t *counters, uint32_t max_depth, uint64_t n_samples,
+                             uint64_t *totals)
+{
+    hipLaunchKernelGGL(k_accumulate_stats, dim3(1), dim3(64), 0, s, counters, max_depth, n_samples, totals);
+}
+
+void launch_scale_copy(hipStream_t s, const float4 *src, float4 *dst, uint64_t n, float scale)
+{
+    uint32_t blocks = (uint32_t)((n + 255u) / 256u);
+    if (!blocks) return;
+    hipLaunchKernelGGL(k_scale_copy, dim3(blocks), dim3(256), 0, s, src, dst, n, scale);
+}
+
+}  // namespace ptx

@@ -1,0 +1,172 @@
+// traverse.h -- closest-hit query over the compressed 8-wide BVH: what traceRayEXT
+// (rgen.glsl:66-78) does in the reference's driver/hardware, as per-lane software for CDNA4.
+// Per-lane "while-while" traversal, ray-octant ordered, short stack of (node group, hit mask)
+// pairs.  Result is order-independent: closest t, ties -> lowest (instance, primitive); box
+// culling keeps t == t_best candidates.
+#pragma once
+
+#include "bvh8.h"
+#include "pt_math.h"
+
+namespace ptx {
+
+struct HitRec {
+    float t, u, v;
+    uint32_t tri;    // index into the leaf-ordered TriRec array; 0xFFFFFFFF = miss
+};
+
+struct Words80 { uint32_t w[20]; };
+
+PT_HD Words80 load_node(const Bvh8Node *nodes, uint32_t i)
+{
+    Words80 r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 *p = reinterpret_cast<const uint4 *>(nodes + i);
+    uint4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+    r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
+    r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
+    r.w[8] = c.x; r.w[9] = c.y; r.w[10] = c.z; r.w[11] = c.w;
+    r.w[12] = d.x; r.w[13] = d.y; r.w[14] = d.z; r.w[15] = d.w;
+    r.w[16] = e.x; r.w[17] = e.y; r.w[18] = e.z; r.w[19] = e.w;
+#else
+    memcpy(r.w, nodes + i, 80);
+#endif
+    return r;
+}
+
+PT_HD uint32_t popc32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popc(x);
+#else
+    return (uint32_t)__builtin_popcount(x);
+#endif
+}
+PT_HD uint32_t msb32(uint32_t x)   // x != 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return 31u - (uint32_t)__clz((int)x);
+#else
+    return 31u - (uint32_t)__builtin_clz(x);
+#endif
+}
+PT_HD uint32_t lsb32(uint32_t x)   // x != 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__ffs((int)x) - 1u;
+#else
+    return (uint32_t)__builtin_ctz(x);
+#endif
+}
+PT_HD float fma_f(float a, float b, float c)
+{
+    // box tests only need to be conservative, not reproducible: use the hardware FMA
+    return __builtin_fmaf(a, b, c);
+}
+PT_HD float byte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }
+
+struct TraverseStats { uint32_t nodes, tris; };
+
+// Stack: any type with push(uint32_t, uint32_t), pop(uint32_t&, uint32_t&), empty().
+template <class Stack, bool kStats>
+PT_HD void traverse_closest(const Bvh8Node *nodes, uint32_t n_nodes, const TriRec *tris, f3 o, f3 d, float t_min,
+                            float t_max, Stack &stack, HitRec &hit, TraverseStats *stats)
+{
+    hit.t = t_max; hit.u = 0.0f; hit.v = 0.0f; hit.tri = 0xFFFFFFFFu;
+    uint32_t best_inst = 0xFFFFFFFFu, best_prim = 0xFFFFFFFFu;
+    // rays with a non-finite origin or direction hit nothing (same rule as the oracle)
+    if (n_nodes == 0 || !finite3(o) || !finite3(d)) return;
+
+    // reciprocal direction for the slab tests; |d| clamped away from 0 so no 0*inf NaNs arise
+    const float tiny = 1e-18f;
+    float dx = fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x);
+    float dy = fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y);
+    float dz = fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z);
+    float idx = 1.0f / dx, idy = 1.0f / dy, idz = 1.0f / dz;
+    const bool negx = dx < 0.0f, negy = dy < 0.0f, negz = dz < 0.0f;
+    const uint32_t octinv = (negx ? 0u : 4u) | (negy ? 0u : 2u) | (negz ? 0u : 1u);
+
+    uint32_t ng_base = 0, ng_mask = 0x80000000u;   // root: one pending "child" in the top bit
+    // the root's hit bit must decode to slot with relative index 0: imask byte is 0
+
+    for (;;) {
+        uint32_t tg_base = 0, tg_mask = 0;
+        if (ng_mask & 0xFF000000u) {
+            uint32_t b = msb32(ng_mask);
+            uint32_t imask = ng_mask & 0xFFu;
+            ng_mask &= ~(1u << b);
+            if (ng_mask & 0xFF000000u) stack.push(ng_base, ng_mask);
+            uint32_t slot = (b - 24u) ^ octinv;
+            uint32_t rel = popc32(imask & ((1u << slot) - 1u));
+            Words80 n = load_node(nodes, ng_base + rel);
+            if (kStats) stats->nodes++;
+
+            float px = u2f(n.w[0]), py = u2f(n.w[1]), pz = u2f(n.w[2]);
+            uint32_t ew = n.w[3];
+            float sx = u2f((ew & 0xFFu) << 23), sy = u2f(((ew >> 8) & 0xFFu) << 23), sz = u2f(((ew >> 16) & 0xFFu) << 23);
+            uint32_t node_imask = ew >> 24;
+            float ax = sx * idx, ay = sy * idy, az = sz * idz;            // t per quantisation step
+            float bx = (px - o.x) * idx, by = (py - o.y) * idy, bz = (pz - o.z) * idz;
+
+            uint32_t hitmask = 0;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                uint32_t meta4 = n.w[6 + half];
+                // near / far planes by ray octant
+                uint32_t qlx = n.w[8 + half], qly = n.w[10 + half], qlz = n.w[12 + half];
+                uint32_t qhx = n.w[14 + half], qhy = n.w[16 + half], qhz = n.w[18 + half];
+                uint32_t nx4 = negx ? qhx : qlx, fx4 = negx ? qlx : qhx;
+                uint32_t ny4 = negy ? qhy : qly, fy4 = negy ? qly : qhy;
+                uint32_t nz4 = negz ? qhz : qlz, fz4 = negz ? qlz : qhz;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t meta = (meta4 >> (8 * k)) & 0xFFu;
+                    float tnx = fma_f(byte_f(nx4, k), ax, bx), tfx = fma_f(byte_f(fx4, k), ax, bx);
+                    float tny = fma_f(byte_f(ny4, k), ay, by), tfy = fma_f(byte_f(fy4, k), ay, by);
+                    float tnz = fma_f(byte_f(nz4, k), az, bz), tfz = fma_f(byte_f(fz4, k), az, bz);
+                    float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, t_min));
+                    float tf = fminf(fminf(tfx, tfy), fminf(tfz, hit.t));
+                    bool inner = (meta & 0x18u) == 0x18u;
+                    uint32_t bit = (inner ? (meta ^ octinv) : meta) & 31u;
+                    uint32_t bits = meta >> 5;
+                    if (tn <= tf) hitmask |= bits << bit;
+                }
+            }
+            ng_base = n.w[4];
+            ng_mask = (hitmask & 0xFF000000u) | node_imask;
+            tg_base = n.w[5];
+            tg_mask = hitmask & 0x00FFFFFFu;
+        }
+
+        while (tg_mask) {
+            uint32_t i = lsb32(tg_mask);
+            tg_mask &= tg_mask - 1u;
+            uint32_t ti = tg_base + i;
+#if defined(__HIP_DEVICE_COMPILE__)
+            const float4 *tp = reinterpret_cast<const float4 *>(tris + ti);
+            float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
+            f3 v0 = mk3(r0.x, r0.y, r0.z), v1 = mk3(r1.x, r1.y, r1.z), v2 = mk3(r2.x, r2.y, r2.z);
+            uint32_t inst = __float_as_uint(r0.w), prim = __float_as_uint(r1.w);
+#else
+            const TriRec &tr = tris[ti];
+            f3 v0 = mk3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = mk3(tr.v1[0], tr.v1[1], tr.v1[2]),
+               v2 = mk3(tr.v2[0], tr.v2[1], tr.v2[2]);
+            uint32_t inst = tr.instance, prim = tr.prim;
+#endif
+            if (kStats) stats->tris++;
+            float t, u, v;
+            if (tri_test(o, d, v0, v1, v2, t_min, t_max, t, u, v) &&
+                hit_better(t, inst, prim, hit.t, best_inst, best_prim)) {
+                hit.t = t; hit.u = u; hit.v = v; hit.tri = ti;
+                best_inst = inst; best_prim = prim;
+            }
+        }
+
+        if (!(ng_mask & 0xFF000000u)) {
+            if (stack.empty()) break;
+            stack.pop(ng_base, ng_mask);
+        }
+    }
+}
+
+}  // namespace ptx

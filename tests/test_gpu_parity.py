@@ -1,0 +1,65 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on identical inputs.
+Bar: bit-exact for the primary-hit (instance, primitive) ids AND, because the build pins every
+fp32 expression (no FMA contraction, shared sin/cos polynomial), for the RGBA32F accumulation,
+normal and depth images as well."""
+import numpy as np
+import pytest
+
+from helpers import SEED, assert_images_bit_equal, cornell, gpu_render, lion_boulder, rel_mse, upload
+
+pytestmark = pytest.mark.gpu
+
+
+def cornell_cam(oracle, aspect=1.0):
+    # SURVEY.md 8d, config C1
+    return oracle.camera_matrices([0, 1.0, 3.9], oracle.yaw_quat(0), np.deg2rad(np.float32(40)), aspect, 0.1, 1000.0)
+
+
+@pytest.fixture(scope="module")
+def cornell_pair(oracle, gpu_ctx_factory):
+    ing = cornell()
+    ctx = gpu_ctx_factory()
+    upload(ctx, ing, oracle)
+    return oracle.scene_from_ingest(ing), ctx
+
+
+def test_cornell_64x64_16spp_bit_exact(oracle, cornell_pair):
+    sc, ctx = cornell_pair
+    cam = cornell_cam(oracle)
+    want = sc.render(cam, 64, 64, 16, SEED, params=oracle.default_params(max_depth=8, flags=1))
+    from path_tracer_amd import capi
+    got = gpu_render(ctx, oracle, cam, 64, 64, 16, params=capi.default_params(max_depth=8))
+    assert_images_bit_equal(got, want, "cornell 64x64x16")
+    st = ctx.stats()
+    assert st["samples"] >= 64 * 64 * 16
+
+
+def test_render_batch_equals_repeated_render(oracle, cornell_pair):
+    sc, ctx = cornell_pair
+    cam = cornell_cam(oracle)
+    a = gpu_render(ctx, oracle, cam, 96, 64, 5, batch=True)
+    b = gpu_render(ctx, oracle, cam, 96, 64, 5, batch=False)
+    assert_images_bit_equal(a, b, "batch vs 5x render")
+
+
+def test_cornell_512_depth8_bit_exact(oracle, cornell_pair):
+    sc, ctx = cornell_pair
+    cam = cornell_cam(oracle)
+    from path_tracer_amd import capi
+    want = sc.render(cam, 512, 512, 2, SEED, params=oracle.default_params(max_depth=8))
+    got = gpu_render(ctx, oracle, cam, 512, 512, 2, params=capi.default_params(max_depth=8))
+    assert_images_bit_equal(got, want, "cornell 512x512x2")
+
+
+def test_lion_boulder_textured_bit_exact(oracle, gpu_ctx_factory):
+    ing = lion_boulder()
+    ctx = gpu_ctx_factory()
+    upload(ctx, ing, oracle)
+    sc = oracle.scene_from_ingest(ing)
+    # SURVEY.md 8d C4 close-up on the lion (the app's default camera at render_window.rs:436 sees both as specks)
+    cam = oracle.camera_matrices([2.0, 0.25, 0.6], oracle.yaw_quat(0), np.deg2rad(np.float32(70)), 320 / 180, 0.1, 1000.0)
+    want = sc.render(cam, 320, 180, 4, SEED)
+    got = gpu_render(ctx, oracle, cam, 320, 180, 4)
+    assert_images_bit_equal(got, want, "lion+boulder 320x180x4")
+    assert want["stats"]["textured_hits"] > 0
+    assert rel_mse(got["albedo"], want["albedo"]) == 0.0
