@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark: samples/s (and Mrays/s) on the Sponza 1920x1080 config.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (torch.distributed / RCCL when N > 1, launched by torch.distributed.run).
+A "step" = one pass of the hot path over one batch: --spp-per-step (default 16) samples per pixel of
+the whole 1920x1080 image = 33.2 M pixel-samples, through the reference-mirroring host
+(path_tracer_amd.host.Renderer -> C ABI -> HIP kernels).  Multi-GPU is the spp partition of
+BASELINE.json: every rank holds the full scene + BVH, renders its own sample indices
+(rng_sample_offset) into its own accumulation buffer, and the buffers are combined by ONE RCCL
+reduce at the end of the timed region (weak scaling: per-GPU work fixed).
+
+Rank 0 prints one JSON line; see DESIGN.md "Measurement" for every field.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 0x1234567
+WORKLOADS = {
+    # scene, (gltf, offset) list, camera pos, yaw deg, fov deg, resolution
+    "sponza_1080p": dict(items=[("sponza/Sponza.gltf", (0, 0, 0))], pos=[-8.0, 1.6, 0.0], yaw=-90.0, fov=70.0,
+                         res=(1920, 1080), geometry="procedural stand-in (Sponza.bin is missing from the reference checkout)"),
+    "spheres_720p": dict(items=[("spheres/spheres.gltf", (0, 0, 0))], pos=[7.0, 2.0, 0.0], yaw=90.0, fov=70.0,
+                         res=(1280, 720), geometry="procedural stand-in (spheres.bin is missing from the reference checkout)"),
+    "lion_boulder_1080p": dict(items=[("lion_head_2k/lion_head_2k.gltf", (2, 0, 0)), ("boulder_01_2k/boulder_01_2k.gltf", (-2, 0, 0))],
+                               pos=[2.0, 0.25, 0.6], yaw=0.0, fov=70.0, res=(1920, 1080), geometry="real"),
+    "cornell_512": dict(items=[("cornell/cornell.gltf", (0, 0, 0))], pos=[0.0, 1.0, 3.9], yaw=0.0, fov=40.0,
+                        res=(512, 512), geometry="real"),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 80, 48, 32, 16
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--workload", default="sponza_1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--max-depth", type=int, default=16)
+    ap.add_argument("--cpu-baseline-spp", type=int, default=2, help="0 disables the CPU leg")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from path_tracer_amd import capi, host, standins
+    wl = WORKLOADS[args.workload]
+    assets = os.path.join(ROOT, "assets")
+    if local_rank == 0:
+        standins.ensure_standins(assets)
+    if dist is not None:
+        dist.barrier()
+
+    W, H = wl["res"]
+    limits = capi.default_limits(max_vertices=10 ** 7, max_indices=3 * 10 ** 7)
+    t0 = time.time()
+    r = host.Renderer(W, H, local_rank, limits)
+    for rel, off in wl["items"]:
+        r.import_gltf(os.path.join(assets, rel), off)
+    r.set_camera(wl["pos"], host.yaw_quat(wl["yaw"]), np.deg2rad(np.float32(wl["fov"])), 0.1, 1000.0)
+    r.set_seed(SEED, fixed=True)
+    spp = args.spp_per_step
+    total_spp = (args.steps + args.warmup) * spp
+    # rank g renders sample indices [g*total_spp, (g+1)*total_spp) of the job's budget
+    params = capi.default_params(max_depth=args.max_depth, rng_sample_offset=rank * total_spp)
+    r.set_params(params)
+    ctx = r._ctx()
+    for _ in range(args.warmup):
+        r.record_commands_batch(spp)
+    ctx.synchronize()
+    load_s = time.time() - t0
+
+    red = None
+    if dist is not None:
+        red = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:%d" % local_rank)
+
+    # ---------------- timed region: exactly K steps + the one accumulation reduce ----------------
+    ctx.set_profiling(1)
+    ctx.reset_stats()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        r.record_commands_batch(spp)
+    if dist is not None:
+        ctx.export_albedo_device(red.data_ptr(), red.numel() * 4, 1.0)
+        dist.reduce(red, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            torch.cuda.synchronize()
+            ctx.import_albedo_device(red.data_ptr(), red.numel() * 4, 1.0 / world)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    st = ctx.stats()
+    ctx.set_profiling(0)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([st["samples"], st["rays"]], dtype=torch.float64, device="cuda:%d" % local_rank)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        job_samples, job_rays = float(cnt[0].item()), float(cnt[1].item())
+    else:
+        job_samples, job_rays = float(st["samples"]), float(st["rays"])
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (k_extend, BVH traversal): algorithmic bytes per launch ----
+        ctx.set_profiling(2)
+        ctx.reset_stats()
+        r.record_commands_batch(spp)          # one untimed instrumented step: nodes fetched / triangles tested
+        ist = ctx.stats()
+        ctx.set_profiling(0)
+        nodes_per_ray = ist["nodes_fetched"] / max(1, ist["rays"])
+        tris_per_ray = ist["tris_tested"] / max(1, ist["rays"])
+        bytes_per_ray = nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES + RAY_BYTES + HIT_BYTES
+        launches = max(1, st["extend_launches"])
+        rays_per_launch = st["rays"] / launches
+        avg_launch_s = st["extend_ms"] * 1e-3 / launches
+        achieved = bytes_per_ray * rays_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        traffic = None
+        if os.path.exists(args.traffic_json):
+            try:
+                tj = json.load(open(args.traffic_json))
+                if tj.get("workload") == args.workload:
+                    traffic = tj.get("hbm_bytes_per_extend_launch")
+            except Exception:
+                traffic = None
+        roofline = dict(bound="hbm", kernel="k_extend", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                        algorithmic_bytes_per_ray=round(bytes_per_ray, 1), nodes_per_ray=round(nodes_per_ray, 2),
+                        tris_per_ray=round(tris_per_ray, 2), rays_per_launch=round(rays_per_launch, 1),
+                        avg_launch_ms=round(avg_launch_s * 1e3, 4), launches=int(launches),
+                        extend_ms=round(st["extend_ms"], 2), shade_ms=round(st["shade_ms"], 2))
+
+        cpu = None
+        parity = None
+        if args.cpu_baseline_spp > 0:
+            cpu, parity = cpu_baseline(r, wl, assets, W, H, args.cpu_baseline_spp, args.max_depth)
+
+        out = {
+            "metric": "samples/sec (Mrays/s) Sponza 1080p at 1/2/4/8 MI355X; rel-MSE vs ref",
+            "value": round(job_samples / elapsed, 1),
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "resolution": "%dx%d" % (W, H), "spp_per_step": spp,
+                       "max_depth": args.max_depth, "seed": SEED, "geometry": wl["geometry"],
+                       "parallelism": "spp-partition x%d, scene+BVH replicated, one RCCL reduce" % world if world > 1 else "single GPU",
+                       "triangles": int(st["bvh_triangles"]), "bvh_nodes": int(st["bvh_nodes"])},
+            "mrays_per_s": round(job_rays / elapsed / 1e6, 1),
+            "rays_per_sample": round(job_rays / max(1.0, job_samples), 3),
+            "scene_load_s": round(load_s, 2),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "parity": parity,
+        }
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(r, wl, assets, W, H, spp, max_depth):
+    """Times the CPU oracle (oracle/pt_oracle.c, a port of the reference's shaders -- the reference itself
+    has no CPU path) on a bounded sample of the same workload, and checks the GPU image against it."""
+    from oracle import pyoracle as O
+    from oracle.gltf_ingest import IngestedScene
+    from path_tracer_amd import capi, host
+    ing = IngestedScene()
+    for rel, off in wl["items"]:
+        ing.import_gltf(os.path.join(assets, rel), off, decode_image=host.decode_image)   # same texels as the GPU side
+    sc = O.scene_from_ingest(ing)
+    cam = O.camera_matrices(wl["pos"], O.yaw_quat(wl["yaw"]), np.deg2rad(np.float32(wl["fov"])), W / H, 0.1, 1000.0)
+    threads = min(os.cpu_count() or 1, 16)
+    t = time.perf_counter()
+    want = sc.render(cam, W, H, spp, SEED, params=O.default_params(max_depth=max_depth), threads=threads)
+    dt = time.perf_counter() - t
+    # the same spp frames on the GPU, from a fresh accumulation, through the C ABI
+    ctx = r._ctx()
+    ctx.resize(W, H)
+    gcam = host.camera_matrices(wl["pos"], host.yaw_quat(wl["yaw"]), np.deg2rad(np.float32(wl["fov"])), W / H, 0.1, 1000.0)
+    u = capi.Uniforms(1, SEED, 0, 0.1, 100.0, (0, 0, 0))
+    ctx.render_batch(u, gcam, spp, capi.default_params(max_depth=max_depth))
+    got = ctx.read_image(capi.IMAGE_ALBEDO)
+    ids = ctx.read_image(capi.IMAGE_PRIMARY_ID)
+    a = np.asarray(got, np.float64)[..., :3]
+    b = np.asarray(want["albedo"], np.float64)[..., :3]
+    rel_mse = float(np.mean((a - b) ** 2 / (b * b + 1e-2)))
+    parity = {"spp": spp, "primary_ids_bit_exact": bool(np.array_equal(ids, want["ids"])),
+              "albedo_bit_exact": bool(np.array_equal(got.view(np.uint32), want["albedo"].view(np.uint32))),
+              "rel_mse": rel_mse, "rel_mse_eps": 1e-2}
+    cpu = {"value": round(want["stats"]["samples"] / dt, 1), "unit": "samples/s", "cores": threads, "kind": "port",
+           "mrays_per_s": round(want["stats"]["rays"] / dt / 1e6, 3),
+           "sample": "%d spp of the full %dx%d frame (%d pixel-samples, %.1f s)" % (spp, W, H, want["stats"]["samples"], dt)}
+    return cpu, parity
+
+
+if __name__ == "__main__":
+    main()

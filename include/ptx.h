@@ -117,6 +117,7 @@ typedef struct {
     double total_ms;              /* GPU time of all render calls while profiling is on */
     uint64_t bvh_nodes, bvh_triangles, bvh_bytes;
     uint32_t bvh_depth, _pad;
+    uint64_t nodes_fetched, tris_tested;   /* BVH nodes fetched / triangles tested; counted only at profiling level 2 */
 } ptx_stats;
 
 typedef struct ptx_context ptx_context;
@@ -183,7 +184,7 @@ int ptx_import_albedo_device(ptx_context *ctx, const void *device_src, uint64_t 
 int ptx_reduce_accumulation(ptx_context **ctxs, int n, int root);
 
 int ptx_synchronize(ptx_context *ctx);
-int ptx_set_profiling(ptx_context *ctx, int enabled);   /* HIP-event timing of each stage launch */
+int ptx_set_profiling(ptx_context *ctx, int level);     /* 0 off; 1 HIP-event timing of each stage launch; 2 also the instrumented traversal kernel (slower) */
 int ptx_get_stats(ptx_context *ctx, ptx_stats *stats);  /* synchronises */
 int ptx_reset_stats(ptx_context *ctx);
 const char *ptx_last_error(ptx_context *ctx);           /* ctx may be NULL: last error of ptx_create on this thread */

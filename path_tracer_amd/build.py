@@ -17,6 +17,28 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
          "-Wall", "-Wno-unused-function", "-x", "hip"]
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(HERE, "libpt_host.so")
+HOST_SOURCES = ["pth_capi.cpp", "pth_renderer.cpp", "pth_scene.cpp", "pth_image.cpp"]
+CXX = os.environ.get("CXX", "g++")
+
+
+def build_host(force=False, verbose=False):
+    """The C++ host mirror (Renderer / Scene / glTF / image codecs): plain g++, talks to the
+    kernels only through the C ABI of include/ptx.h."""
+    deps = [os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR)] + [os.path.join(HERE, "..", "include", "ptx.h"), __file__]
+    if (not force and os.path.exists(HOST_LIB) and os.path.exists(LIB)
+            and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in deps)):
+        return HOST_LIB
+    cmd = [CXX, "-O2", "-std=c++17", "-Wall", "-Wextra", "-ffp-contract=off", "-fPIC", "-shared", "-o", HOST_LIB]
+    cmd += [os.path.join(HOST_DIR, f) for f in HOST_SOURCES]
+    cmd += ["-L" + HERE, "-lptx_amd", "-Wl,-rpath,$ORIGIN", "-lz"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -50,4 +72,5 @@ def build_library(force=False, verbose=False):
 
 if __name__ == "__main__":
     build_library(force="--force" in sys.argv, verbose=True)
-    print(LIB)
+    build_host(force="--force" in sys.argv, verbose=True)
+    print(LIB, HOST_LIB)

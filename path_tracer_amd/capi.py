@@ -45,7 +45,8 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("hits", C.c_uint64), ("samples", C.c_uint64),
                 ("extend_launches", C.c_uint64), ("extend_ms", C.c_double), ("shade_ms", C.c_double),
                 ("total_ms", C.c_double), ("bvh_nodes", C.c_uint64), ("bvh_triangles", C.c_uint64),
-                ("bvh_bytes", C.c_uint64), ("bvh_depth", C.c_uint32), ("_pad", C.c_uint32)]
+                ("bvh_bytes", C.c_uint64), ("bvh_depth", C.c_uint32), ("_pad", C.c_uint32),
+                ("nodes_fetched", C.c_uint64), ("tris_tested", C.c_uint64)]
 
 
 EXPORTS = [
@@ -217,8 +218,8 @@ class Context:
     def synchronize(self):
         self._check(self._L.ptx_synchronize(self.handle))
 
-    def set_profiling(self, on):
-        self._check(self._L.ptx_set_profiling(self.handle, int(bool(on))))
+    def set_profiling(self, level):
+        self._check(self._L.ptx_set_profiling(self.handle, int(level)))
 
     def stats(self):
         s = Stats()

@@ -66,10 +66,11 @@ struct ptx_context {
     HitRec *d_hits = nullptr;
     float4 *d_results = nullptr;
     uint32_t *d_counters = nullptr;
-    uint64_t *d_totals = nullptr;           // rays, hits, samples
+    uint64_t *d_totals = nullptr;           // rays, hits, samples, nodes fetched, triangles tested
 
     // profiling
     bool profiling = false;
+    bool count_traversal = false;           // profiling level 2: instrumented extend kernel
     std::vector<EventPair> events;          // recorded, not yet read
     std::vector<EventPair> event_pool;      // free
     double extend_ms = 0, shade_ms = 0, total_ms = 0;
@@ -209,8 +210,8 @@ int ptx_create_with_limits(int device_ordinal, const ptx_limits *limits, ptx_con
     CREATE_TRY(hipSetDevice(device_ordinal));
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_TRY(hipMalloc((void **)&c->d_counters, kNumCounters * sizeof(uint32_t)));
-    CREATE_TRY(hipMalloc((void **)&c->d_totals, 3 * sizeof(uint64_t)));
-    CREATE_TRY(hipMemset(c->d_totals, 0, 3 * sizeof(uint64_t)));
+    CREATE_TRY(hipMalloc((void **)&c->d_totals, 5 * sizeof(uint64_t)));
+    CREATE_TRY(hipMemset(c->d_totals, 0, 5 * sizeof(uint64_t)));
     CREATE_TRY(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
     float lut[256]; srgb_lut(lut);
     CREATE_TRY(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
@@ -477,7 +478,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
             if (c->profiling) {
                 EventPair e = get_events(c, 0);
                 HIP_TRY(c, hipEventRecord(e.a, c->stream));
-                launch_extend(c->stream, sc, f, rin, c->d_counters + b, n_paths, c->d_hits);
+                launch_extend(c->stream, sc, f, rin, c->d_counters + b, n_paths, c->d_hits, c->count_traversal ? c->d_totals + 3 : nullptr);
                 HIP_TRY(c, hipEventRecord(e.b, c->stream));
                 c->events.push_back(e);
                 EventPair e2 = get_events(c, 1);
@@ -486,7 +487,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
                 HIP_TRY(c, hipEventRecord(e2.b, c->stream));
                 c->events.push_back(e2);
             } else {
-                launch_extend(c->stream, sc, f, rin, c->d_counters + b, n_paths, c->d_hits);
+                launch_extend(c->stream, sc, f, rin, c->d_counters + b, n_paths, c->d_hits, c->count_traversal ? c->d_totals + 3 : nullptr);
                 launch_shade(c->stream, sc, f, img, b, rin, c->d_hits, c->d_counters, n_paths, rout, c->d_results);
             }
         }
@@ -576,6 +577,7 @@ int ptx_set_profiling(ptx_context *c, int enabled)
 {
     if (!c) return PTX_ERR_INVALID;
     c->profiling = enabled != 0;
+    c->count_traversal = enabled >= 2;
     return PTX_OK;
 }
 
@@ -586,10 +588,10 @@ int ptx_get_stats(ptx_context *c, ptx_stats *s)
     if (int r = bind(c)) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_events(c);
-    uint64_t t[3];
+    uint64_t t[5];
     HIP_TRY(c, hipMemcpy(t, c->d_totals, sizeof t, hipMemcpyDeviceToHost));
     memset(s, 0, sizeof *s);
-    s->rays = t[0]; s->hits = t[1]; s->samples = t[2];
+    s->rays = t[0]; s->hits = t[1]; s->samples = t[2]; s->nodes_fetched = t[3]; s->tris_tested = t[4];
     s->extend_launches = c->extend_launches; s->extend_ms = c->extend_ms; s->shade_ms = c->shade_ms; s->total_ms = c->total_ms;
     s->bvh_nodes = c->n_nodes; s->bvh_triangles = c->n_tris;
     s->bvh_bytes = (uint64_t)c->n_nodes * sizeof(Bvh8Node) + c->n_tris * (sizeof(TriRec) + sizeof(ShadeRec));
@@ -603,7 +605,7 @@ int ptx_reset_stats(ptx_context *c)
     if (int r = bind(c)) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_events(c);
-    HIP_TRY(c, hipMemset(c->d_totals, 0, 3 * sizeof(uint64_t)));
+    HIP_TRY(c, hipMemset(c->d_totals, 0, 5 * sizeof(uint64_t)));
     c->extend_ms = c->shade_ms = c->total_ms = 0; c->extend_launches = 0;
     return PTX_OK;
 }

@@ -69,7 +69,7 @@ constexpr uint32_t kMaxBvhDepth = kLdsStack + kOvfStack;
 
 void launch_raygen(hipStream_t s, const FrameDev &f, uint32_t n_paths, RayRec *rays, uint32_t *counters);
 void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, const RayRec *rays, const uint32_t *count,
-                   uint32_t capacity, HitRec *hits);
+                   uint32_t capacity, HitRec *hits, uint64_t *trav_totals /* NULL: uninstrumented */);
 void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
                   const RayRec *rays_in, const HitRec *hits, uint32_t *counters, uint32_t capacity, RayRec *rays_out,
                   float4 *results);

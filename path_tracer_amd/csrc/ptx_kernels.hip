@@ -79,10 +79,12 @@ struct LaneStack {
     __device__ __forceinline__ bool empty() const { return sp == 0; }
 };
 
+template <bool kStats>
 __global__ void __launch_bounds__(kExtendBlock) k_extend(SceneDev sc, float t_min, float t_max,
                                                           const RayRec *__restrict__ rays,
                                                           const uint32_t *__restrict__ count,
-                                                          HitRec *__restrict__ hits)
+                                                          HitRec *__restrict__ hits,
+                                                          unsigned long long *__restrict__ trav_totals)
 {
     __shared__ uint2 s_stack[kLdsStack * kExtendBlock];
     uint32_t i = blockIdx.x * kExtendBlock + threadIdx.x;
@@ -93,9 +95,15 @@ __global__ void __launch_bounds__(kExtendBlock) k_extend(SceneDev sc, float t_mi
     st.lds = s_stack + threadIdx.x;
     st.sp = 0;
     HitRec h;
-    traverse_closest<LaneStack, false>(sc.nodes, sc.n_nodes, sc.tris, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z),
-                                       t_min, t_max, st, h, nullptr);
+    TraverseStats ts = {0u, 0u};
+    traverse_closest<LaneStack, kStats>(sc.nodes, sc.n_nodes, sc.tris, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z),
+                                        t_min, t_max, st, h, &ts);
     *reinterpret_cast<float4 *>(hits + i) = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+    if (kStats) {
+        // instrumented variant (ptx_set_profiling level 2): nodes fetched / triangles tested
+        atomicAdd(&trav_totals[0], (unsigned long long)ts.nodes);
+        atomicAdd(&trav_totals[1], (unsigned long long)ts.tris);
+    }
 }
 
 // ---------------------------------------------------------------- shade
@@ -277,11 +285,16 @@ void launch_raygen(hipStream_t s, const FrameDev &f, uint32_t n_paths, RayRec *r
 }
 
 void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, const RayRec *rays, const uint32_t *count,
-                   uint32_t capacity, HitRec *hits)
+                   uint32_t capacity, HitRec *hits, uint64_t *trav_totals)
 {
     uint32_t blocks = (capacity + kExtendBlock - 1u) / kExtendBlock;
     if (!blocks) return;
-    hipLaunchKernelGGL(k_extend, dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, hits);
+    if (trav_totals)
+        hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, hits,
+                           reinterpret_cast<unsigned long long *>(trav_totals));
+    else
+        hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, hits,
+                           (unsigned long long *)nullptr);
 }
 
 void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
