@@ -199,7 +199,10 @@ class IngestedScene:
             image = doc["images"][doc["textures"][tex["index"]]["source"]]
             ident = "gltf_%s" % image["uri"]                                     # material.rs:59-61
             if ident not in self.texture_lookup:                                 # graphics.rs:396-398
-                rgba = (decode_image or decode_image_pil)(os.path.join(base, image["uri"]))
+                rgba = np.asarray((decode_image or decode_image_pil)(os.path.join(base, image["uri"])), np.uint8)
+                if rgba.shape[2] == 3:                                            # graphics.rs:507-516
+                    rgba = np.concatenate([rgba, np.full(rgba.shape[:2] + (1,), 255, np.uint8)], axis=2)
+                rgba = np.ascontiguousarray(rgba)
                 self.textures.append((rgba, 1))                                  # R8G8B8A8_SRGB
                 self.texture_lookup[ident] = len(self.textures) - 1
             m["has_base_texture"] = 1

@@ -41,7 +41,9 @@ def test_renderer_frames_match_oracle_and_dirty_rules(oracle, tmp_path):
     fov = np.deg2rad(np.float32(40.0))
     r.set_camera([0.0, 1.0, 3.9], host.yaw_quat(0.0), fov)
     r.set_seed(SEED, fixed=True)
-    r.record_commands()
+    r.record_commands()                  # camera-dirty; the || short-circuit leaves the scene flag set
+    assert r.accumulated_count == 0
+    r.record_commands()                  # scene-dirty
     assert r.accumulated_count == 0
     r.record_commands()
     assert r.accumulated_count == 1
