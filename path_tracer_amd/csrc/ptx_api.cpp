@@ -62,6 +62,7 @@ struct ptx_context {
     // wavefront state
     uint64_t path_capacity = 0;
     uint64_t target_paths = 8u << 20;
+    uint32_t extend_waves = 4096;           // persistent grid of the traversal kernel
     RayRec *d_rays[2] = {nullptr, nullptr};
     HitRec *d_hits = nullptr;
     float4 *d_results = nullptr;
@@ -213,6 +214,8 @@ int ptx_create_with_limits(int device_ordinal, const ptx_limits *limits, ptx_con
     CREATE_TRY(hipMalloc((void **)&c->d_totals, 5 * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->d_totals, 0, 5 * sizeof(uint64_t)));
     CREATE_TRY(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
+    c->extend_waves = extend_resident_waves(device_ordinal);
+    if (const char *ew = getenv("PTX_EXTEND_WAVES")) { long v = strtol(ew, nullptr, 10); if (v > 0) c->extend_waves = (uint32_t)v; }
     float lut[256]; srgb_lut(lut);
     CREATE_TRY(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
 #undef CREATE_TRY
@@ -478,7 +481,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
             if (c->profiling) {
                 EventPair e = get_events(c, 0);
                 HIP_TRY(c, hipEventRecord(e.a, c->stream));
-                launch_extend(c->stream, sc, f, rin, c->d_counters + b, n_paths, c->d_hits, c->count_traversal ? c->d_totals + 3 : nullptr);
+                launch_extend(c->stream, sc, f, rin, c->d_counters + b, c->d_counters + kNextBase + b, n_paths, c->extend_waves, c->d_hits, c->count_traversal ? c->d_totals + 3 : nullptr);
                 HIP_TRY(c, hipEventRecord(e.b, c->stream));
                 c->events.push_back(e);
                 EventPair e2 = get_events(c, 1);
@@ -487,7 +490,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
                 HIP_TRY(c, hipEventRecord(e2.b, c->stream));
                 c->events.push_back(e2);
             } else {
-                launch_extend(c->stream, sc, f, rin, c->d_counters + b, n_paths, c->d_hits, c->count_traversal ? c->d_totals + 3 : nullptr);
+                launch_extend(c->stream, sc, f, rin, c->d_counters + b, c->d_counters + kNextBase + b, n_paths, c->extend_waves, c->d_hits, c->count_traversal ? c->d_totals + 3 : nullptr);
                 launch_shade(c->stream, sc, f, img, b, rin, c->d_hits, c->d_counters, n_paths, rout, c->d_results);
             }
         }

@@ -57,10 +57,11 @@ struct ImagesDev {
     float4 *albedo; float4 *normal; float *depth; uint2 *ids;
 };
 
-// counters[0 .. max_depth]: live rays entering each bounce; counters[kHitCounter]: hits of the chunk
+// counters[0 .. max_depth]: live rays entering each bounce; counters[kHitCounter]: hits of the chunk;
 constexpr uint32_t kMaxDepthLimit = 64;
 constexpr uint32_t kHitCounter = kMaxDepthLimit + 1;
-constexpr uint32_t kNumCounters = kMaxDepthLimit + 2;
+constexpr uint32_t kNextBase = kMaxDepthLimit + 2;      // counters[kNextBase + b]: fetch cursor of bounce b's extend
+constexpr uint32_t kNumCounters = 2 * kMaxDepthLimit + 3;
 
 // traversal stack: entries held in LDS per lane, remainder in private memory
 constexpr int kLdsStack = 12;
@@ -68,8 +69,11 @@ constexpr int kOvfStack = 20;
 constexpr uint32_t kMaxBvhDepth = kLdsStack + kOvfStack;
 
 void launch_raygen(hipStream_t s, const FrameDev &f, uint32_t n_paths, RayRec *rays, uint32_t *counters);
+// `next`: the bounce's fetch cursor (zeroed by raygen); `max_waves`: resident-wave budget of the persistent grid
 void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, const RayRec *rays, const uint32_t *count,
-                   uint32_t capacity, HitRec *hits, uint64_t *trav_totals /* NULL: uninstrumented */);
+                   uint32_t *next, uint32_t capacity, uint32_t max_waves, HitRec *hits,
+                   uint64_t *trav_totals /* NULL: uninstrumented */);
+uint32_t extend_resident_waves(int device);
 void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
                   const RayRec *rays_in, const HitRec *hits, uint32_t *counters, uint32_t capacity, RayRec *rays_out,
                   float4 *results);

@@ -14,6 +14,8 @@
 
 #include "ptx_kernels.h"
 
+#include <algorithm>
+
 namespace ptx {
 
 namespace {
@@ -60,10 +62,15 @@ __global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, Ra
 }
 
 // ---------------------------------------------------------------- extend
+// Persistent waves with dynamic ray fetch: a wave keeps stepping its 64 traversal state machines
+// and, whenever kRefill or more lanes have finished, refills them from the bounce's ray queue with
+// one atomic per wave.  Path lengths through the BVH are heavy-tailed; without the refill a wave
+// runs at the pace of its slowest ray (11 % VALU lane utilisation measured, profiles/r01a).
 struct LaneStack {
     uint2 *lds;                 // this lane's column of the workgroup's LDS stack
     uint2 ovf[kOvfStack];
     int sp;
+    __device__ __forceinline__ void clear() { sp = 0; }
     __device__ __forceinline__ void push(uint32_t base, uint32_t mask)
     {
         if (sp < kLdsStack) lds[sp * kExtendBlock] = make_uint2(base, mask);
@@ -79,30 +86,67 @@ struct LaneStack {
     __device__ __forceinline__ bool empty() const { return sp == 0; }
 };
 
+constexpr int kRefill = 16;     // refill once this many lanes are idle
+
 template <bool kStats>
 __global__ void __launch_bounds__(kExtendBlock) k_extend(SceneDev sc, float t_min, float t_max,
                                                           const RayRec *__restrict__ rays,
                                                           const uint32_t *__restrict__ count,
+                                                          uint32_t *__restrict__ next,
                                                           HitRec *__restrict__ hits,
                                                           unsigned long long *__restrict__ trav_totals)
 {
     __shared__ uint2 s_stack[kLdsStack * kExtendBlock];
-    uint32_t i = blockIdx.x * kExtendBlock + threadIdx.x;
-    if (i >= *count) return;
-    const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
-    float4 r0 = rp[0], r1 = rp[1];
+    const uint32_t n = *count;
     LaneStack st;
     st.lds = s_stack + threadIdx.x;
     st.sp = 0;
-    HitRec h;
-    TraverseStats ts = {0u, 0u};
-    traverse_closest<LaneStack, kStats>(sc.nodes, sc.n_nodes, sc.tris, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z),
-                                        t_min, t_max, st, h, &ts);
-    *reinterpret_cast<float4 *>(hits + i) = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+    Traversal<LaneStack, kStats> tr;
+    tr.ng_mask = 0; tr.tg_mask = 0;
+    bool active = false;        // this lane holds an unfinished ray
+    bool exhausted = false;     // wave-uniform: the queue has been handed out completely
+    uint32_t ray = 0;
+    unsigned long long tot_nodes = 0, tot_tris = 0;
+
+    for (;;) {
+        unsigned long long idle = __ballot(!active);
+        if (!exhausted && __popcll(idle) >= kRefill) {
+            uint32_t n_idle = (uint32_t)__popcll(idle);
+            uint32_t base = 0;
+            if (threadIdx.x == (uint32_t)(__ffsll((long long)idle) - 1)) base = atomicAdd(next, n_idle);
+            base = __shfl(base, __ffsll((long long)idle) - 1, 64);
+            if (!active) {
+                uint32_t i = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (i < n) {
+                    const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
+                    float4 r0 = rp[0], r1 = rp[1];
+                    tr.init(sc.n_nodes, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), t_min, t_max, st);
+                    ray = i;
+                    active = true;
+                }
+            }
+            exhausted = base + n_idle >= n;
+        }
+        unsigned long long live = __ballot(active);
+        if (live == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        // step until enough lanes have finished to make a refill worthwhile (or, once the queue
+        // is empty, until every lane is done)
+        const int stop_at = exhausted ? 0 : (64 - kRefill);
+        do {
+            if (active && tr.step(sc.nodes, sc.tris, st)) {
+                *reinterpret_cast<float4 *>(hits + ray) = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
+                if (kStats) { tot_nodes += tr.stats.nodes; tot_tris += tr.stats.tris; }
+                active = false;
+            }
+        } while (__popcll(__ballot(active)) > stop_at);
+    }
     if (kStats) {
         // instrumented variant (ptx_set_profiling level 2): nodes fetched / triangles tested
-        atomicAdd(&trav_totals[0], (unsigned long long)ts.nodes);
-        atomicAdd(&trav_totals[1], (unsigned long long)ts.tris);
+        atomicAdd(&trav_totals[0], tot_nodes);
+        atomicAdd(&trav_totals[1], tot_tris);
     }
 }
 
@@ -285,16 +329,24 @@ void launch_raygen(hipStream_t s, const FrameDev &f, uint32_t n_paths, RayRec *r
 }
 
 void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, const RayRec *rays, const uint32_t *count,
-                   uint32_t capacity, HitRec *hits, uint64_t *trav_totals)
+                   uint32_t *next, uint32_t capacity, uint32_t max_waves, HitRec *hits, uint64_t *trav_totals)
 {
-    uint32_t blocks = (capacity + kExtendBlock - 1u) / kExtendBlock;
+    uint32_t blocks = std::min((capacity + kExtendBlock - 1u) / kExtendBlock, max_waves);
     if (!blocks) return;
     if (trav_totals)
-        hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, hits,
-                           reinterpret_cast<unsigned long long *>(trav_totals));
+        hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, next,
+                           hits, reinterpret_cast<unsigned long long *>(trav_totals));
     else
-        hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, hits,
-                           (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, next,
+                           hits, (unsigned long long *)nullptr);
+}
+
+uint32_t extend_resident_waves(int device)
+{
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend<false>, kExtendBlock, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    return (uint32_t)per_cu * (uint32_t)cus;
 }
 
 void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,

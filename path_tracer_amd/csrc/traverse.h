@@ -1,8 +1,11 @@
 // traverse.h -- closest-hit query over the compressed 8-wide BVH: what traceRayEXT
 // (rgen.glsl:66-78) does in the reference's driver/hardware, as per-lane software for CDNA4.
-// Per-lane "while-while" traversal, ray-octant ordered, short stack of (node group, hit mask)
-// pairs.  Result is order-independent: closest t, ties -> lowest (instance, primitive); box
-// culling keeps t == t_best candidates.
+//
+// The query is a small state machine (Traversal::step) so that a persistent wave can keep all
+// 64 lanes busy: one step = at most one node visit (8 quantised box tests, ray-octant ordered)
+// plus at most one triangle test, and a lane whose ray has finished is refilled with a new ray
+// by the caller.  Short stack of (node group, hit mask) pairs.  The result is order-independent:
+// closest t, ties -> lowest (instance, primitive); box culling keeps t == t_best candidates.
 #pragma once
 
 #include "bvh8.h"
@@ -58,115 +61,139 @@ PT_HD uint32_t lsb32(uint32_t x)   // x != 0
     return (uint32_t)__builtin_ctz(x);
 #endif
 }
-PT_HD float fma_f(float a, float b, float c)
-{
-    // box tests only need to be conservative, not reproducible: use the hardware FMA
-    return __builtin_fmaf(a, b, c);
-}
+// box tests only need to be conservative, not reproducible: use the hardware FMA
+PT_HD float fma_f(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 PT_HD float byte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }
 
 struct TraverseStats { uint32_t nodes, tris; };
 
-// Stack: any type with push(uint32_t, uint32_t), pop(uint32_t&, uint32_t&), empty().
+// Stack: any type with push(uint32_t, uint32_t), pop(uint32_t&, uint32_t&), empty(), clear().
 template <class Stack, bool kStats>
-PT_HD void traverse_closest(const Bvh8Node *nodes, uint32_t n_nodes, const TriRec *tris, f3 o, f3 d, float t_min,
-                            float t_max, Stack &stack, HitRec &hit, TraverseStats *stats)
-{
-    hit.t = t_max; hit.u = 0.0f; hit.v = 0.0f; hit.tri = 0xFFFFFFFFu;
-    uint32_t best_inst = 0xFFFFFFFFu, best_prim = 0xFFFFFFFFu;
-    // rays with a non-finite origin or direction hit nothing (same rule as the oracle)
-    if (n_nodes == 0 || !finite3(o) || !finite3(d)) return;
+struct Traversal {
+    // ray
+    f3 o, d;
+    float t_min, t_max;
+    float idx, idy, idz;        // reciprocal direction for the slab tests
+    uint32_t octinv;
+    // traversal state
+    uint32_t ng_base, ng_mask;  // node group: first-child index | hit bits 31..24, imask bits 7..0
+    uint32_t tg_base, tg_mask;  // triangle group: first triangle | pending bits 23..0
+    HitRec hit;
+    uint32_t best_inst, best_prim;
+    TraverseStats stats;
 
-    // reciprocal direction for the slab tests; |d| clamped away from 0 so no 0*inf NaNs arise
-    const float tiny = 1e-18f;
-    float dx = fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x);
-    float dy = fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y);
-    float dz = fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z);
-    float idx = 1.0f / dx, idy = 1.0f / dy, idz = 1.0f / dz;
-    const bool negx = dx < 0.0f, negy = dy < 0.0f, negz = dz < 0.0f;
-    const uint32_t octinv = (negx ? 0u : 4u) | (negy ? 0u : 2u) | (negz ? 0u : 1u);
+    // Returns false if the ray needs no traversal at all (empty scene, non-finite ray: such
+    // rays hit nothing, the same rule as the oracle).
+    PT_HD bool init(uint32_t n_nodes, f3 org, f3 dir, float tmin, float tmax, Stack &stack)
+    {
+        o = org; d = dir; t_min = tmin; t_max = tmax;
+        hit.t = tmax; hit.u = 0.0f; hit.v = 0.0f; hit.tri = 0xFFFFFFFFu;
+        best_inst = 0xFFFFFFFFu; best_prim = 0xFFFFFFFFu;
+        stats.nodes = 0; stats.tris = 0;
+        stack.clear();
+        tg_base = 0; tg_mask = 0;
+        ng_base = 0; ng_mask = 0;
+        if (n_nodes == 0 || !finite3(org) || !finite3(dir)) return false;
+        // |d| clamped away from 0 so that no 0 * inf NaN can arise in the slab tests
+        const float tiny = 1e-18f;
+        float dx = fabsf(dir.x) > tiny ? dir.x : copysignf(tiny, dir.x);
+        float dy = fabsf(dir.y) > tiny ? dir.y : copysignf(tiny, dir.y);
+        float dz = fabsf(dir.z) > tiny ? dir.z : copysignf(tiny, dir.z);
+        idx = 1.0f / dx; idy = 1.0f / dy; idz = 1.0f / dz;
+        octinv = (dx < 0.0f ? 0u : 4u) | (dy < 0.0f ? 0u : 2u) | (dz < 0.0f ? 0u : 1u);
+        ng_mask = 0x80000000u;   // the root as the single pending child of a virtual group (imask 0 -> index 0)
+        return true;
+    }
 
-    uint32_t ng_base = 0, ng_mask = 0x80000000u;   // root: one pending "child" in the top bit
-    // the root's hit bit must decode to slot with relative index 0: imask byte is 0
+    PT_HD void node_step(const Bvh8Node *nodes, Stack &stack)
+    {
+        uint32_t b = msb32(ng_mask);
+        uint32_t imask = ng_mask & 0xFFu;
+        ng_mask &= ~(1u << b);
+        if (ng_mask & 0xFF000000u) stack.push(ng_base, ng_mask);
+        uint32_t slot = (b - 24u) ^ octinv;
+        uint32_t rel = popc32(imask & ((1u << slot) - 1u));
+        Words80 n = load_node(nodes, ng_base + rel);
+        if (kStats) stats.nodes++;
 
-    for (;;) {
-        uint32_t tg_base = 0, tg_mask = 0;
-        if (ng_mask & 0xFF000000u) {
-            uint32_t b = msb32(ng_mask);
-            uint32_t imask = ng_mask & 0xFFu;
-            ng_mask &= ~(1u << b);
-            if (ng_mask & 0xFF000000u) stack.push(ng_base, ng_mask);
-            uint32_t slot = (b - 24u) ^ octinv;
-            uint32_t rel = popc32(imask & ((1u << slot) - 1u));
-            Words80 n = load_node(nodes, ng_base + rel);
-            if (kStats) stats->nodes++;
+        float px = u2f(n.w[0]), py = u2f(n.w[1]), pz = u2f(n.w[2]);
+        uint32_t ew = n.w[3];
+        float sx = u2f((ew & 0xFFu) << 23), sy = u2f(((ew >> 8) & 0xFFu) << 23), sz = u2f(((ew >> 16) & 0xFFu) << 23);
+        float ax = sx * idx, ay = sy * idy, az = sz * idz;            // t per quantisation step
+        float bx = (px - o.x) * idx, by = (py - o.y) * idy, bz = (pz - o.z) * idz;
+        const bool negx = !(octinv & 4u), negy = !(octinv & 2u), negz = !(octinv & 1u);
 
-            float px = u2f(n.w[0]), py = u2f(n.w[1]), pz = u2f(n.w[2]);
-            uint32_t ew = n.w[3];
-            float sx = u2f((ew & 0xFFu) << 23), sy = u2f(((ew >> 8) & 0xFFu) << 23), sz = u2f(((ew >> 16) & 0xFFu) << 23);
-            uint32_t node_imask = ew >> 24;
-            float ax = sx * idx, ay = sy * idy, az = sz * idz;            // t per quantisation step
-            float bx = (px - o.x) * idx, by = (py - o.y) * idy, bz = (pz - o.z) * idz;
-
-            uint32_t hitmask = 0;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                uint32_t meta4 = n.w[6 + half];
-                // near / far planes by ray octant
-                uint32_t qlx = n.w[8 + half], qly = n.w[10 + half], qlz = n.w[12 + half];
-                uint32_t qhx = n.w[14 + half], qhy = n.w[16 + half], qhz = n.w[18 + half];
-                uint32_t nx4 = negx ? qhx : qlx, fx4 = negx ? qlx : qhx;
-                uint32_t ny4 = negy ? qhy : qly, fy4 = negy ? qly : qhy;
-                uint32_t nz4 = negz ? qhz : qlz, fz4 = negz ? qlz : qhz;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    uint32_t meta = (meta4 >> (8 * k)) & 0xFFu;
-                    float tnx = fma_f(byte_f(nx4, k), ax, bx), tfx = fma_f(byte_f(fx4, k), ax, bx);
-                    float tny = fma_f(byte_f(ny4, k), ay, by), tfy = fma_f(byte_f(fy4, k), ay, by);
-                    float tnz = fma_f(byte_f(nz4, k), az, bz), tfz = fma_f(byte_f(fz4, k), az, bz);
-                    float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, t_min));
-                    float tf = fminf(fminf(tfx, tfy), fminf(tfz, hit.t));
-                    bool inner = (meta & 0x18u) == 0x18u;
-                    uint32_t bit = (inner ? (meta ^ octinv) : meta) & 31u;
-                    uint32_t bits = meta >> 5;
-                    if (tn <= tf) hitmask |= bits << bit;
-                }
-            }
-            ng_base = n.w[4];
-            ng_mask = (hitmask & 0xFF000000u) | node_imask;
-            tg_base = n.w[5];
-            tg_mask = hitmask & 0x00FFFFFFu;
-        }
-
-        while (tg_mask) {
-            uint32_t i = lsb32(tg_mask);
-            tg_mask &= tg_mask - 1u;
-            uint32_t ti = tg_base + i;
+        uint32_t hitmask = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-            const float4 *tp = reinterpret_cast<const float4 *>(tris + ti);
-            float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
-            f3 v0 = mk3(r0.x, r0.y, r0.z), v1 = mk3(r1.x, r1.y, r1.z), v2 = mk3(r2.x, r2.y, r2.z);
-            uint32_t inst = __float_as_uint(r0.w), prim = __float_as_uint(r1.w);
-#else
-            const TriRec &tr = tris[ti];
-            f3 v0 = mk3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = mk3(tr.v1[0], tr.v1[1], tr.v1[2]),
-               v2 = mk3(tr.v2[0], tr.v2[1], tr.v2[2]);
-            uint32_t inst = tr.instance, prim = tr.prim;
+#pragma unroll
 #endif
-            if (kStats) stats->tris++;
-            float t, u, v;
-            if (tri_test(o, d, v0, v1, v2, t_min, t_max, t, u, v) &&
-                hit_better(t, inst, prim, hit.t, best_inst, best_prim)) {
-                hit.t = t; hit.u = u; hit.v = v; hit.tri = ti;
-                best_inst = inst; best_prim = prim;
+        for (int half = 0; half < 2; ++half) {
+            uint32_t meta4 = n.w[6 + half];
+            // near / far planes by ray octant
+            uint32_t qlx = n.w[8 + half], qly = n.w[10 + half], qlz = n.w[12 + half];
+            uint32_t qhx = n.w[14 + half], qhy = n.w[16 + half], qhz = n.w[18 + half];
+            uint32_t nx4 = negx ? qhx : qlx, fx4 = negx ? qlx : qhx;
+            uint32_t ny4 = negy ? qhy : qly, fy4 = negy ? qly : qhy;
+            uint32_t nz4 = negz ? qhz : qlz, fz4 = negz ? qlz : qhz;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int k = 0; k < 4; ++k) {
+                uint32_t meta = (meta4 >> (8 * k)) & 0xFFu;
+                float tnx = fma_f(byte_f(nx4, k), ax, bx), tfx = fma_f(byte_f(fx4, k), ax, bx);
+                float tny = fma_f(byte_f(ny4, k), ay, by), tfy = fma_f(byte_f(fy4, k), ay, by);
+                float tnz = fma_f(byte_f(nz4, k), az, bz), tfz = fma_f(byte_f(fz4, k), az, bz);
+                float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, t_min));
+                float tf = fminf(fminf(tfx, tfy), fminf(tfz, hit.t));
+                bool inner = (meta & 0x18u) == 0x18u;
+                uint32_t bit = (inner ? (meta ^ octinv) : meta) & 31u;
+                uint32_t bits = meta >> 5;
+                if (tn <= tf) hitmask |= bits << bit;
             }
         }
+        ng_base = n.w[4];
+        ng_mask = (hitmask & 0xFF000000u) | (ew >> 24);
+        tg_base = n.w[5];
+        tg_mask = hitmask & 0x00FFFFFFu;
+    }
 
-        if (!(ng_mask & 0xFF000000u)) {
-            if (stack.empty()) break;
-            stack.pop(ng_base, ng_mask);
+    PT_HD void tri_step(const TriRec *tris)
+    {
+        uint32_t i = lsb32(tg_mask);
+        tg_mask &= tg_mask - 1u;
+        uint32_t ti = tg_base + i;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float4 *tp = reinterpret_cast<const float4 *>(tris + ti);
+        float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
+        f3 v0 = mk3(r0.x, r0.y, r0.z), v1 = mk3(r1.x, r1.y, r1.z), v2 = mk3(r2.x, r2.y, r2.z);
+        uint32_t inst = __float_as_uint(r0.w), prim = __float_as_uint(r1.w);
+#else
+        const TriRec &tr = tris[ti];
+        f3 v0 = mk3(tr.v0[0], tr.v0[1], tr.v0[2]), v1 = mk3(tr.v1[0], tr.v1[1], tr.v1[2]),
+           v2 = mk3(tr.v2[0], tr.v2[1], tr.v2[2]);
+        uint32_t inst = tr.instance, prim = tr.prim;
+#endif
+        if (kStats) stats.tris++;
+        float t, u, v;
+        if (tri_test(o, d, v0, v1, v2, t_min, t_max, t, u, v) && hit_better(t, inst, prim, hit.t, best_inst, best_prim)) {
+            hit.t = t; hit.u = u; hit.v = v; hit.tri = ti;
+            best_inst = inst; best_prim = prim;
         }
     }
-}
+
+    // One unit of work.  Returns true when the query is complete (result in `hit`).
+    PT_HD bool step(const Bvh8Node *nodes, const TriRec *tris, Stack &stack)
+    {
+        if (tg_mask == 0) {
+            if (!(ng_mask & 0xFF000000u)) {
+                if (stack.empty()) return true;
+                stack.pop(ng_base, ng_mask);
+            }
+            node_step(nodes, stack);
+        }
+        if (tg_mask) tri_step(tris);
+        return false;
+    }
+};
 
 }  // namespace ptx

@@ -14,6 +14,7 @@ struct HostStack {
     void push(uint32_t base, uint32_t mask) { b[sp] = base; m[sp] = mask; ++sp; if (sp > max_sp) max_sp = sp; }
     void pop(uint32_t &base, uint32_t &mask) { --sp; base = b[sp]; mask = m[sp]; }
     bool empty() const { return sp == 0; }
+    void clear() { sp = 0; }
 };
 struct Check {
     Bvh8 bvh;
@@ -50,10 +51,12 @@ void bvhcheck_trace(void *h, const float *rays, uint64_t n, float t_min, float t
     Check *c = (Check *)h;
     uint64_t nv = 0, tt = 0; int ms = 0;
     for (uint64_t i = 0; i < n; ++i) {
-        HostStack st; HitRec hit; TraverseStats ts = {0, 0};
+        HostStack st;
         f3 o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
-        traverse_closest<HostStack, true>(c->bvh.nodes.data(), (uint32_t)c->bvh.nodes.size(), c->tris.data(), o, d,
-                                          t_min, t_max, st, hit, &ts);
+        Traversal<HostStack, true> tr;
+        tr.init((uint32_t)c->bvh.nodes.size(), o, d, t_min, t_max, st);
+        while (!tr.step(c->bvh.nodes.data(), c->tris.data(), st)) {}
+        const HitRec &hit = tr.hit; const TraverseStats &ts = tr.stats;
         nv += ts.nodes; tt += ts.tris; if (st.max_sp > ms) ms = st.max_sp;
         tuv[i * 3] = hit.t; tuv[i * 3 + 1] = hit.u; tuv[i * 3 + 2] = hit.v;
         if (hit.tri != 0xFFFFFFFFu) { ids[i * 2] = c->tris[hit.tri].instance; ids[i * 2 + 1] = c->tris[hit.tri].prim; }
