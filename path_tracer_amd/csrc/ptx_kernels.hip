@@ -15,6 +15,7 @@
 #include "ptx_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace ptx {
 
@@ -86,7 +87,6 @@ struct LaneStack {
     __device__ __forceinline__ bool empty() const { return sp == 0; }
 };
 
-constexpr int kRefill = 16;     // refill once this many lanes are idle
 
 template <bool kStats>
 __global__ void __launch_bounds__(kExtendBlock) k_extend(SceneDev sc, float t_min, float t_max,
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(kExtendBlock) k_extend(SceneDev sc, float t_mi
                                                           const uint32_t *__restrict__ count,
                                                           uint32_t *__restrict__ next,
                                                           HitRec *__restrict__ hits,
-                                                          unsigned long long *__restrict__ trav_totals)
+                                                          unsigned long long *__restrict__ trav_totals, int kRefill)
 {
     __shared__ uint2 s_stack[kLdsStack * kExtendBlock];
     const uint32_t n = *count;
@@ -331,14 +331,15 @@ void launch_raygen(hipStream_t s, const FrameDev &f, uint32_t n_paths, RayRec *r
 void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, const RayRec *rays, const uint32_t *count,
                    uint32_t *next, uint32_t capacity, uint32_t max_waves, HitRec *hits, uint64_t *trav_totals)
 {
+    static const int refill = [] { const char *e = getenv("PTX_REFILL"); int v = e ? atoi(e) : 32; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
     uint32_t blocks = std::min((capacity + kExtendBlock - 1u) / kExtendBlock, max_waves);
     if (!blocks) return;
     if (trav_totals)
         hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, next,
-                           hits, reinterpret_cast<unsigned long long *>(trav_totals));
+                           hits, reinterpret_cast<unsigned long long *>(trav_totals), refill);
     else
         hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, next,
-                           hits, (unsigned long long *)nullptr);
+                           hits, (unsigned long long *)nullptr, refill);
 }
 
 uint32_t extend_resident_waves(int device)
