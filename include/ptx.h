@@ -118,6 +118,7 @@ typedef struct {
     uint64_t bvh_nodes, bvh_triangles, bvh_bytes;
     uint32_t bvh_depth, _pad;
     uint64_t nodes_fetched, tris_tested;   /* BVH nodes fetched / triangles tested; counted only at profiling level 2 */
+    uint64_t wave_sched[6];                /* level 2: wave iterations, node blocks, lanes in them, triangle blocks, lanes in them, refills */
 } ptx_stats;
 
 typedef struct ptx_context ptx_context;

@@ -46,7 +46,7 @@ class Stats(C.Structure):
                 ("extend_launches", C.c_uint64), ("extend_ms", C.c_double), ("shade_ms", C.c_double),
                 ("total_ms", C.c_double), ("bvh_nodes", C.c_uint64), ("bvh_triangles", C.c_uint64),
                 ("bvh_bytes", C.c_uint64), ("bvh_depth", C.c_uint32), ("_pad", C.c_uint32),
-                ("nodes_fetched", C.c_uint64), ("tris_tested", C.c_uint64)]
+                ("nodes_fetched", C.c_uint64), ("tris_tested", C.c_uint64), ("wave_sched", C.c_uint64 * 6)]
 
 
 EXPORTS = [
@@ -71,9 +71,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError("%s is missing: run `python -m path_tracer_amd.build` (hipcc, gfx950)" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+    path = os.environ.get("PTX_LIB", LIB_PATH)      # developer override: an alternative build of the same library
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: run `python -m path_tracer_amd.build` (hipcc, gfx950)" % path)
+    L = C.CDLL(path)
     vp = C.c_void_p
     L.ptx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.ptx_create_with_limits.argtypes = [C.c_int, C.POINTER(Limits), C.POINTER(vp)]
@@ -224,7 +225,9 @@ class Context:
     def stats(self):
         s = Stats()
         self._check(self._L.ptx_get_stats(self.handle, C.byref(s)))
-        return {k: getattr(s, k) for k, _ in Stats._fields_ if not k.startswith("_")}
+        d = {k: getattr(s, k) for k, _ in Stats._fields_ if not k.startswith("_")}
+        d["wave_sched"] = list(d["wave_sched"])
+        return d
 
     def reset_stats(self):
         self._check(self._L.ptx_reset_stats(self.handle))

@@ -61,7 +61,7 @@ struct ptx_context {
 
     // wavefront state
     uint64_t path_capacity = 0;
-    uint64_t target_paths = 8u << 20;
+    uint64_t target_paths = 16u << 20;
     uint32_t extend_waves = 4096;           // persistent grid of the traversal kernel
     RayRec *d_rays[2] = {nullptr, nullptr};
     HitRec *d_hits = nullptr;
@@ -211,8 +211,8 @@ int ptx_create_with_limits(int device_ordinal, const ptx_limits *limits, ptx_con
     CREATE_TRY(hipSetDevice(device_ordinal));
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_TRY(hipMalloc((void **)&c->d_counters, kNumCounters * sizeof(uint32_t)));
-    CREATE_TRY(hipMalloc((void **)&c->d_totals, 5 * sizeof(uint64_t)));
-    CREATE_TRY(hipMemset(c->d_totals, 0, 5 * sizeof(uint64_t)));
+    CREATE_TRY(hipMalloc((void **)&c->d_totals, 11 * sizeof(uint64_t)));
+    CREATE_TRY(hipMemset(c->d_totals, 0, 11 * sizeof(uint64_t)));
     CREATE_TRY(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
     c->extend_waves = extend_resident_waves(device_ordinal);
     if (const char *ew = getenv("PTX_EXTEND_WAVES")) { long v = strtol(ew, nullptr, 10); if (v > 0) c->extend_waves = (uint32_t)v; }
@@ -591,10 +591,11 @@ int ptx_get_stats(ptx_context *c, ptx_stats *s)
     if (int r = bind(c)) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_events(c);
-    uint64_t t[5];
+    uint64_t t[11];
     HIP_TRY(c, hipMemcpy(t, c->d_totals, sizeof t, hipMemcpyDeviceToHost));
     memset(s, 0, sizeof *s);
     s->rays = t[0]; s->hits = t[1]; s->samples = t[2]; s->nodes_fetched = t[3]; s->tris_tested = t[4];
+    for (int i = 0; i < 6; ++i) s->wave_sched[i] = t[5 + i];
     s->extend_launches = c->extend_launches; s->extend_ms = c->extend_ms; s->shade_ms = c->shade_ms; s->total_ms = c->total_ms;
     s->bvh_nodes = c->n_nodes; s->bvh_triangles = c->n_tris;
     s->bvh_bytes = (uint64_t)c->n_nodes * sizeof(Bvh8Node) + c->n_tris * (sizeof(TriRec) + sizeof(ShadeRec));
@@ -608,7 +609,7 @@ int ptx_reset_stats(ptx_context *c)
     if (int r = bind(c)) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_events(c);
-    HIP_TRY(c, hipMemset(c->d_totals, 0, 5 * sizeof(uint64_t)));
+    HIP_TRY(c, hipMemset(c->d_totals, 0, 11 * sizeof(uint64_t)));
     c->extend_ms = c->shade_ms = c->total_ms = 0; c->extend_launches = 0;
     return PTX_OK;
 }

@@ -88,13 +88,20 @@ struct LaneStack {
 };
 
 
+struct ExtendSched { int refill, node_min, tri_min; uint32_t chunk; };   // lane-count thresholds (wave-uniform)
+
+#ifndef PTX_EXTEND_WAVES_PER_EU
+#define PTX_EXTEND_WAVES_PER_EU 4
+#endif
+
 template <bool kStats>
-__global__ void __launch_bounds__(kExtendBlock) k_extend(SceneDev sc, float t_min, float t_max,
+__global__ void __launch_bounds__(kExtendBlock) __attribute__((amdgpu_waves_per_eu(PTX_EXTEND_WAVES_PER_EU, PTX_EXTEND_WAVES_PER_EU)))
+k_extend(SceneDev sc, float t_min, float t_max,
                                                           const RayRec *__restrict__ rays,
                                                           const uint32_t *__restrict__ count,
                                                           uint32_t *__restrict__ next,
                                                           HitRec *__restrict__ hits,
-                                                          unsigned long long *__restrict__ trav_totals, int kRefill)
+                                                          unsigned long long *__restrict__ trav_totals, ExtendSched sched)
 {
     __shared__ uint2 s_stack[kLdsStack * kExtendBlock];
     const uint32_t n = *count;
@@ -107,25 +114,41 @@ __global__ void __launch_bounds__(kExtendBlock) k_extend(SceneDev sc, float t_mi
     bool exhausted = false;     // wave-uniform: the queue has been handed out completely
     uint32_t ray = 0;
     unsigned long long tot_nodes = 0, tot_tris = 0;
+    unsigned long long w_iters = 0, w_node_blocks = 0, w_node_lanes = 0, w_tri_blocks = 0, w_tri_lanes = 0, w_refills = 0;   // wave-level (kStats)
+
+    // Rays are handed out in two levels: a wave reserves a chunk of the queue with one atomic and
+    // refills its idle lanes from that chunk.  (One atomic per refill on a single word saturates
+    // at ~88 M/s chip-wide and was the bottleneck: MI355X_MICROARCH.md "dequeue".)
+    uint32_t chunk_next = 0, chunk_end = 0;          // wave-uniform
+    const uint32_t chunk = sched.chunk;
 
     for (;;) {
         unsigned long long idle = __ballot(!active);
-        if (!exhausted && __popcll(idle) >= kRefill) {
-            uint32_t n_idle = (uint32_t)__popcll(idle);
-            uint32_t base = 0;
-            if (threadIdx.x == (uint32_t)(__ffsll((long long)idle) - 1)) base = atomicAdd(next, n_idle);
-            base = __shfl(base, __ffsll((long long)idle) - 1, 64);
-            if (!active) {
-                uint32_t i = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                if (i < n) {
+        if (!exhausted && __popcll(idle) >= sched.refill) {
+            if (kStats) w_refills++;
+            for (int pass = 0; pass < 2 && idle != 0ull; ++pass) {
+                if (chunk_next == chunk_end) {
+                    uint32_t base = 0;
+                    if (threadIdx.x == 0) base = atomicAdd(next, chunk);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (base >= n) { exhausted = true; break; }
+                    chunk_next = base;
+                    chunk_end = (n - base < chunk) ? n : base + chunk;
+                }
+                uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                uint32_t avail = chunk_end - chunk_next;
+                if (!active && rank < avail) {
+                    uint32_t i = chunk_next + rank;
                     const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
                     float4 r0 = rp[0], r1 = rp[1];
                     tr.init(sc.n_nodes, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), t_min, t_max, st);
                     ray = i;
                     active = true;
                 }
+                uint32_t n_idle = (uint32_t)__popcll(idle);
+                chunk_next += (n_idle < avail) ? n_idle : avail;
+                idle = __ballot(!active);
             }
-            exhausted = base + n_idle >= n;
         }
         unsigned long long live = __ballot(active);
         if (live == 0) {
@@ -134,12 +157,29 @@ __global__ void __launch_bounds__(kExtendBlock) k_extend(SceneDev sc, float t_mi
         }
         // step until enough lanes have finished to make a refill worthwhile (or, once the queue
         // is empty, until every lane is done)
-        const int stop_at = exhausted ? 0 : (64 - kRefill);
+        const int stop_at = exhausted ? 0 : (64 - sched.refill);
         do {
-            if (active && tr.step(sc.nodes, sc.tris, st)) {
-                *reinterpret_cast<float4 *>(hits + ray) = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
-                if (kStats) { tot_nodes += tr.stats.nodes; tot_tris += tr.stats.tris; }
-                active = false;
+            // Node visits and triangle tests are two long instruction streams; run each only when
+            // enough lanes want it (or nothing else can make progress), so neither executes for a
+            // handful of lanes while the rest of the wave idles.
+            bool want_node = active && tr.wants_node();
+            const int nb = __popcll(__ballot(want_node));
+            const int tb = __popcll(__ballot(active && tr.wants_tri()));
+            const bool run_node = nb > 0 && (nb >= sched.node_min || tb < sched.tri_min);
+            if (kStats) { w_iters++; if (run_node) { w_node_blocks++; w_node_lanes += nb; } }
+            if (run_node && want_node) {
+                if (tr.next_group(st)) {
+                    tr.node_step(sc.nodes, st);
+                } else {
+                    *reinterpret_cast<float4 *>(hits + ray) = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
+                    if (kStats) { tot_nodes += tr.stats.nodes; tot_tris += tr.stats.tris; }
+                    active = false;
+                }
+            }
+            bool want_tri = active && tr.wants_tri();
+            if (!run_node || __popcll(__ballot(want_tri)) >= sched.tri_min) {
+                if (kStats) { int t2 = __popcll(__ballot(want_tri)); if (t2) { w_tri_blocks++; w_tri_lanes += t2; } }
+                if (want_tri) tr.tri_step(sc.tris);
             }
         } while (__popcll(__ballot(active)) > stop_at);
     }
@@ -147,6 +187,10 @@ __global__ void __launch_bounds__(kExtendBlock) k_extend(SceneDev sc, float t_mi
         // instrumented variant (ptx_set_profiling level 2): nodes fetched / triangles tested
         atomicAdd(&trav_totals[0], tot_nodes);
         atomicAdd(&trav_totals[1], tot_tris);
+        if (threadIdx.x == 0) {
+            atomicAdd(&trav_totals[2], w_iters); atomicAdd(&trav_totals[3], w_node_blocks); atomicAdd(&trav_totals[4], w_node_lanes);
+            atomicAdd(&trav_totals[5], w_tri_blocks); atomicAdd(&trav_totals[6], w_tri_lanes); atomicAdd(&trav_totals[7], w_refills);
+        }
     }
 }
 
@@ -331,7 +375,12 @@ void launch_raygen(hipStream_t s, const FrameDev &f, uint32_t n_paths, RayRec *r
 void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, const RayRec *rays, const uint32_t *count,
                    uint32_t *next, uint32_t capacity, uint32_t max_waves, HitRec *hits, uint64_t *trav_totals)
 {
-    static const int refill = [] { const char *e = getenv("PTX_REFILL"); int v = e ? atoi(e) : 32; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    static const ExtendSched refill = [] {
+        auto knob = [](const char *name, int dflt) { const char *e = getenv(name); int v = e ? atoi(e) : dflt; return v < 1 ? 1 : (v > 64 ? 64 : v); };
+        ExtendSched k; k.refill = knob("PTX_REFILL", 8); k.node_min = knob("PTX_NODE_MIN", 1); k.tri_min = knob("PTX_TRI_MIN", 1);
+        const char *ce = getenv("PTX_CHUNK"); int cv = ce ? atoi(ce) : 128; k.chunk = (uint32_t)(cv < 64 ? 64 : cv);
+        return k;
+    }();
     uint32_t blocks = std::min((capacity + kExtendBlock - 1u) / kExtendBlock, max_waves);
     if (!blocks) return;
     if (trav_totals)

@@ -181,17 +181,29 @@ struct Traversal {
         }
     }
 
+    // Scheduling pieces for a wave that batches node visits and triangle tests separately:
+    // a lane wants a node visit while it has no triangle pending.
+    PT_HD bool wants_node() const { return tg_mask == 0; }
+    PT_HD bool wants_tri() const { return tg_mask != 0; }
+    // Makes a node group current (popping the stack if the current one is spent).  Returns false
+    // when nothing is left: the query is complete (result in `hit`).
+    PT_HD bool next_group(Stack &stack)
+    {
+        if (!(ng_mask & 0xFF000000u)) {
+            if (stack.empty()) return false;
+            stack.pop(ng_base, ng_mask);
+        }
+        return true;
+    }
+
     // One unit of work.  Returns true when the query is complete (result in `hit`).
     PT_HD bool step(const Bvh8Node *nodes, const TriRec *tris, Stack &stack)
     {
-        if (tg_mask == 0) {
-            if (!(ng_mask & 0xFF000000u)) {
-                if (stack.empty()) return true;
-                stack.pop(ng_base, ng_mask);
-            }
+        if (wants_node()) {
+            if (!next_group(stack)) return true;
             node_step(nodes, stack);
         }
-        if (tg_mask) tri_step(tris);
+        if (wants_tri()) tri_step(tris);
         return false;
     }
 };

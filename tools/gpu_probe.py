@@ -45,6 +45,11 @@ for prof in (0, 1):
     st = ctx.stats()
     print("profiling=%d: %.3fs  %.1f Msamples/s  %.1f Mrays/s  rays/sample %.2f  extend %.1f ms (%d launches) shade %.1f ms total %.1f ms" % (
         prof, dt, st["samples"] / dt / 1e6, st["rays"] / dt / 1e6, st["rays"] / st["samples"], st["extend_ms"], st["extend_launches"], st["shade_ms"], st["total_ms"]))
+ctx.set_profiling(2); ctx.reset_stats()
+ctx.render_batch(u, gcam, a.spp, params); st = ctx.stats(); ctx.set_profiling(0)
+ws = st["wave_sched"]
+print("nodes/ray %.2f tris/ray %.2f | wave iters %d node blocks %d (avg lanes %.1f) tri blocks %d (avg lanes %.1f) refills %d | rays %d" % (
+    st["nodes_fetched"] / st["rays"], st["tris_tested"] / st["rays"], ws[0], ws[1], ws[2] / max(1, ws[1]), ws[3], ws[4] / max(1, ws[3]), ws[5], st["rays"]))
 if a.check:
     sc = O.scene_from_ingest(ing)
     t = time.time(); want = sc.render(ocam, W, H, a.check, SEED, params=O.default_params(max_depth=a.depth)); print("oracle %.1fs" % (time.time() - t), want["stats"])
