@@ -22,7 +22,7 @@ namespace ptx {
 namespace {
 
 constexpr int kExtendBlock = 64;    // one wave per workgroup: resources free as soon as the wave retires
-constexpr int kShadeBlock = 256;
+constexpr int kShadeBlock = 1024;   // one queue-tail atomic per 1024 rays: a single word takes only ~88 M atomics/s
 
 __device__ __forceinline__ f3 mat4_mul(const float *m, float x, float y, float z, float w)
 {
@@ -217,7 +217,9 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
                                                         RayRec *__restrict__ rays_out, float4 *__restrict__ results)
 {
     __shared__ float s_lut[256];
-    s_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];
+    __shared__ uint32_t s_wave_live[kShadeBlock / 64], s_wave_hits[kShadeBlock / 64];
+    __shared__ uint32_t s_base;
+    if (threadIdx.x < 256) s_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];
     __syncthreads();
 
     uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x;
@@ -308,18 +310,35 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
         }
     }
 
-    // wave64 compaction: one atomic per wave reserves a contiguous run of the next queue
+    // Compaction: wave64 ballots give each wave its survivor count, the block's 16 counts are
+    // summed through LDS and ONE atomic per block reserves a contiguous run of the next queue.
     unsigned long long live = __ballot(alive);
     unsigned long long hitm = __ballot(was_hit);
-    uint32_t lane = threadIdx.x & 63u;
-    uint32_t base = 0;
-    if (lane == 0) {
-        if (live) base = atomicAdd(&counters[depth + 1u], (uint32_t)__popcll(live));
-        if (hitm) atomicAdd(&counters[kHitCounter], (uint32_t)__popcll(hitm));
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_wave_live[wave] = (uint32_t)__popcll(live); s_wave_hits[wave] = (uint32_t)__popcll(hitm); }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        uint32_t c = lane < kShadeBlock / 64 ? s_wave_live[lane] : 0u;
+        uint32_t h = lane < kShadeBlock / 64 ? s_wave_hits[lane] : 0u;
+        // inclusive scan over the first 16 lanes
+#pragma unroll
+        for (int d = 1; d < kShadeBlock / 64; d <<= 1) {
+            uint32_t t = __shfl_up(c, d, 64);
+            if ((int)lane >= d) c += t;
+        }
+#pragma unroll
+        for (int d = kShadeBlock / 128; d >= 1; d >>= 1) h += __shfl_down(h, d, 64);
+        if (lane < kShadeBlock / 64) s_wave_live[lane] = c;      // inclusive prefix
+        if (lane == kShadeBlock / 64 - 1) {
+            uint32_t base = c ? atomicAdd(&counters[depth + 1u], c) : 0u;
+            s_base = base;
+        }
+        if (lane == 0 && h) atomicAdd(&counters[kHitCounter], h);
     }
-    base = __shfl(base, 0, 64);
+    __syncthreads();
     if (alive) {
-        uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+        uint32_t before = wave ? s_wave_live[wave - 1] : 0u;
+        uint32_t slot = s_base + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
         float4 *op = reinterpret_cast<float4 *>(rays_out + slot);
         op[0] = o0; op[1] = o1; op[2] = o2;
     }
