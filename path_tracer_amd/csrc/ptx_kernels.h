@@ -64,8 +64,8 @@ constexpr uint32_t kNextBase = kMaxDepthLimit + 2;      // counters[kNextBase + 
 constexpr uint32_t kNumCounters = 2 * kMaxDepthLimit + 3;
 
 // traversal stack: entries held in LDS per lane, remainder in private memory
-constexpr int kLdsStack = 12;
-constexpr int kOvfStack = 20;
+constexpr int kLdsStack = 8;
+constexpr int kOvfStack = 24;
 constexpr uint32_t kMaxBvhDepth = kLdsStack + kOvfStack;
 
 void launch_raygen(hipStream_t s, const FrameDev &f, uint32_t n_paths, RayRec *rays, uint32_t *counters);

@@ -88,6 +88,18 @@ struct LaneStack {
 };
 
 
+// Asynchronous fetch of one 80-byte node per lane straight into LDS (gfx950 LDS-DMA,
+// global_load_lds_dwordx4: per-lane global address, destination = wave-uniform base + lane * 16;
+// no VGPRs are held while the load is in flight).  Lanes that do not call it are exec-masked.
+__device__ __forceinline__ void prefetch_node(const Bvh8Node *nodes, uint32_t ni, uint4 *slot)
+{
+    const uint4 *src = reinterpret_cast<const uint4 *>(nodes + ni);
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k),
+                                         (__attribute__((address_space(3))) void *)(slot + k * 64), 16, 0, 0);
+}
+
 struct ExtendSched { int refill, node_min, tri_min; uint32_t chunk; };   // lane-count thresholds (wave-uniform)
 
 #ifndef PTX_EXTEND_WAVES_PER_EU
@@ -104,7 +116,10 @@ k_extend(SceneDev sc, float t_min, float t_max,
                                                           unsigned long long *__restrict__ trav_totals, ExtendSched sched)
 {
     __shared__ uint2 s_stack[kLdsStack * kExtendBlock];
+    // per-lane landing slot of the node prefetch: piece k of lane L at s_node[k * 64 + L]
+    __shared__ uint4 s_node[kExtendBlock * 5];
     const uint32_t n = *count;
+    const uint32_t lane_id = threadIdx.x;
     LaneStack st;
     st.lds = s_stack + threadIdx.x;
     st.sp = 0;
@@ -113,6 +128,7 @@ k_extend(SceneDev sc, float t_min, float t_max,
     bool active = false;        // this lane holds an unfinished ray
     bool exhausted = false;     // wave-uniform: the queue has been handed out completely
     uint32_t ray = 0;
+    uint32_t next_ni = 0xFFFFFFFFu;   // node this lane visits next (already requested), 0xFFFFFFFF: none left
     unsigned long long tot_nodes = 0, tot_tris = 0;
     unsigned long long w_iters = 0, w_node_blocks = 0, w_node_lanes = 0, w_tri_blocks = 0, w_tri_lanes = 0, w_refills = 0;   // wave-level (kStats)
 
@@ -141,7 +157,9 @@ k_extend(SceneDev sc, float t_min, float t_max,
                     uint32_t i = chunk_next + rank;
                     const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
                     float4 r0 = rp[0], r1 = rp[1];
-                    tr.init(sc.n_nodes, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), t_min, t_max, st);
+                    bool go = tr.init(sc.n_nodes, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), t_min, t_max, st);
+                    next_ni = go ? tr.node_pick(st) : 0xFFFFFFFFu;      // the root
+                    if (go) prefetch_node(sc.nodes, next_ni, s_node);
                     ray = i;
                     active = true;
                 }
@@ -162,23 +180,41 @@ k_extend(SceneDev sc, float t_min, float t_max,
             // Node visits and triangle tests are two long instruction streams; run each only when
             // enough lanes want it (or nothing else can make progress), so neither executes for a
             // handful of lanes while the rest of the wave idles.
+            // A lane visits a node when it has no triangle pending; its node was requested one
+            // step earlier (see prefetch_node) so the fetch overlapped the triangle tests.
             bool want_node = active && tr.wants_node();
             const int nb = __popcll(__ballot(want_node));
             const int tb = __popcll(__ballot(active && tr.wants_tri()));
             const bool run_node = nb > 0 && (nb >= sched.node_min || tb < sched.tri_min);
             if (kStats) { w_iters++; if (run_node) { w_node_blocks++; w_node_lanes += nb; } }
-            if (run_node && want_node) {
-                if (tr.next_group(st)) {
-                    tr.node_step(sc.nodes, st);
-                } else {
-                    *reinterpret_cast<float4 *>(hits + ray) = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
-                    if (kStats) { tot_nodes += tr.stats.nodes; tot_tris += tr.stats.tris; }
-                    active = false;
+            if (run_node) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // prefetched nodes have landed
+                if (want_node) {
+                    if (next_ni != 0xFFFFFFFFu) {
+                        Words80 nd;
+                        uint4 a = s_node[lane_id], b = s_node[64 + lane_id], c = s_node[128 + lane_id],
+                              d = s_node[192 + lane_id], e = s_node[256 + lane_id];
+                        nd.w[0] = a.x; nd.w[1] = a.y; nd.w[2] = a.z; nd.w[3] = a.w;
+                        nd.w[4] = b.x; nd.w[5] = b.y; nd.w[6] = b.z; nd.w[7] = b.w;
+                        nd.w[8] = c.x; nd.w[9] = c.y; nd.w[10] = c.z; nd.w[11] = c.w;
+                        nd.w[12] = d.x; nd.w[13] = d.y; nd.w[14] = d.z; nd.w[15] = d.w;
+                        nd.w[16] = e.x; nd.w[17] = e.y; nd.w[18] = e.z; nd.w[19] = e.w;
+                        tr.node_eval(nd);
+                        // the next node to visit is already determined: request it now
+                        next_ni = tr.next_group(st) ? tr.node_pick(st) : 0xFFFFFFFFu;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slot fully read before it is refilled
+                        if (next_ni != 0xFFFFFFFFu) prefetch_node(sc.nodes, next_ni, s_node);
+                    } else {
+                        *reinterpret_cast<float4 *>(hits + ray) = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
+                        if (kStats) { tot_nodes += tr.stats.nodes; tot_tris += tr.stats.tris; }
+                        active = false;
+                    }
                 }
             }
             bool want_tri = active && tr.wants_tri();
-            if (!run_node || __popcll(__ballot(want_tri)) >= sched.tri_min) {
-                if (kStats) { int t2 = __popcll(__ballot(want_tri)); if (t2) { w_tri_blocks++; w_tri_lanes += t2; } }
+            const int tb2 = __popcll(__ballot(want_tri));
+            if (tb2 > 0 && (!run_node || tb2 >= sched.tri_min)) {
+                if (kStats) { w_tri_blocks++; w_tri_lanes += tb2; }
                 if (want_tri) tr.tri_step(sc.tris);
             }
         } while (__popcll(__ballot(active)) > stop_at);

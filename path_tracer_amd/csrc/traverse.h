@@ -105,7 +105,9 @@ struct Traversal {
         return true;
     }
 
-    PT_HD void node_step(const Bvh8Node *nodes, Stack &stack)
+    // Takes the nearest pending child of the current node group (pushing the rest of the group)
+    // and returns its node index.
+    PT_HD uint32_t node_pick(Stack &stack)
     {
         uint32_t b = msb32(ng_mask);
         uint32_t imask = ng_mask & 0xFFu;
@@ -113,7 +115,18 @@ struct Traversal {
         if (ng_mask & 0xFF000000u) stack.push(ng_base, ng_mask);
         uint32_t slot = (b - 24u) ^ octinv;
         uint32_t rel = popc32(imask & ((1u << slot) - 1u));
-        Words80 n = load_node(nodes, ng_base + rel);
+        return ng_base + rel;
+    }
+
+    PT_HD void node_step(const Bvh8Node *nodes, Stack &stack)
+    {
+        uint32_t ni = node_pick(stack);
+        node_eval(load_node(nodes, ni));
+    }
+
+    // 8 quantised box tests against node `n`; the hits become the new node / triangle groups.
+    PT_HD void node_eval(const Words80 &n)
+    {
         if (kStats) stats.nodes++;
 
         float px = u2f(n.w[0]), py = u2f(n.w[1]), pz = u2f(n.w[2]);
@@ -125,8 +138,38 @@ struct Traversal {
 
         uint32_t hitmask = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
+        // gfx950: the six slab planes of a child are three packed-fp32 FMAs (v_pk_fma_f32 does two
+        // lanes' worth of fp32 per issue slot), and the meta bytes of four children are decoded
+        // with byte-parallel integer ops.
+        typedef float pk2 __attribute__((ext_vector_type(2)));
+        const pk2 axx = {ax, ax}, ayy = {ay, ay}, azz = {az, az};
+        const pk2 bxx = {bx, bx}, byy = {by, by}, bzz = {bz, bz};
 #pragma unroll
-#endif
+        for (int half = 0; half < 2; ++half) {
+            uint32_t meta4 = n.w[6 + half];
+            uint32_t qlx = n.w[8 + half], qly = n.w[10 + half], qlz = n.w[12 + half];
+            uint32_t qhx = n.w[14 + half], qhy = n.w[16 + half], qhz = n.w[18 + half];
+            uint32_t nx4 = negx ? qhx : qlx, fx4 = negx ? qlx : qhx;
+            uint32_t ny4 = negy ? qhy : qly, fy4 = negy ? qly : qhy;
+            uint32_t nz4 = negz ? qhz : qlz, fz4 = negz ? qlz : qhz;
+            uint32_t inner4 = ((meta4 & (meta4 << 1)) >> 4) & 0x01010101u;      // 1 in each byte that is an inner child
+            uint32_t bit4 = (meta4 ^ (inner4 * octinv)) & 0x1F1F1F1Fu;          // hit-mask bit position per child
+            uint32_t cnt4 = (meta4 >> 5) & 0x07070707u;                         // unary triangle count (1 for inner)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pk2 qx = {byte_f(nx4, k), byte_f(fx4, k)};
+                pk2 qy = {byte_f(ny4, k), byte_f(fy4, k)};
+                pk2 qz = {byte_f(nz4, k), byte_f(fz4, k)};
+                pk2 tx = __builtin_elementwise_fma(qx, axx, bxx);
+                pk2 ty = __builtin_elementwise_fma(qy, ayy, byy);
+                pk2 tz = __builtin_elementwise_fma(qz, azz, bzz);
+                float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, t_min));
+                float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, hit.t));
+                uint32_t bits = ((cnt4 >> (8 * k)) & 0xFFu) << ((bit4 >> (8 * k)) & 0xFFu);
+                if (tn <= tf) hitmask |= bits;
+            }
+        }
+#else
         for (int half = 0; half < 2; ++half) {
             uint32_t meta4 = n.w[6 + half];
             // near / far planes by ray octant
@@ -135,9 +178,6 @@ struct Traversal {
             uint32_t nx4 = negx ? qhx : qlx, fx4 = negx ? qlx : qhx;
             uint32_t ny4 = negy ? qhy : qly, fy4 = negy ? qly : qhy;
             uint32_t nz4 = negz ? qhz : qlz, fz4 = negz ? qlz : qhz;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
             for (int k = 0; k < 4; ++k) {
                 uint32_t meta = (meta4 >> (8 * k)) & 0xFFu;
                 float tnx = fma_f(byte_f(nx4, k), ax, bx), tfx = fma_f(byte_f(fx4, k), ax, bx);
@@ -151,17 +191,34 @@ struct Traversal {
                 if (tn <= tf) hitmask |= bits << bit;
             }
         }
+#endif
         ng_base = n.w[4];
         ng_mask = (hitmask & 0xFF000000u) | (ew >> 24);
         tg_base = n.w[5];
         tg_mask = hitmask & 0x00FFFFFFu;
     }
 
-    PT_HD void tri_step(const TriRec *tris)
+    // Takes the next pending triangle of the current triangle group.
+    PT_HD uint32_t tri_pick()
     {
         uint32_t i = lsb32(tg_mask);
         tg_mask &= tg_mask - 1u;
-        uint32_t ti = tg_base + i;
+        return tg_base + i;
+    }
+
+    PT_HD void tri_eval(uint32_t ti, f3 v0, f3 v1, f3 v2, uint32_t inst, uint32_t prim)
+    {
+        if (kStats) stats.tris++;
+        float t, u, v;
+        if (tri_test(o, d, v0, v1, v2, t_min, t_max, t, u, v) && hit_better(t, inst, prim, hit.t, best_inst, best_prim)) {
+            hit.t = t; hit.u = u; hit.v = v; hit.tri = ti;
+            best_inst = inst; best_prim = prim;
+        }
+    }
+
+    PT_HD void tri_step(const TriRec *tris)
+    {
+        uint32_t ti = tri_pick();
 #if defined(__HIP_DEVICE_COMPILE__)
         const float4 *tp = reinterpret_cast<const float4 *>(tris + ti);
         float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
@@ -173,12 +230,7 @@ struct Traversal {
            v2 = mk3(tr.v2[0], tr.v2[1], tr.v2[2]);
         uint32_t inst = tr.instance, prim = tr.prim;
 #endif
-        if (kStats) stats.tris++;
-        float t, u, v;
-        if (tri_test(o, d, v0, v1, v2, t_min, t_max, t, u, v) && hit_better(t, inst, prim, hit.t, best_inst, best_prim)) {
-            hit.t = t; hit.u = u; hit.v = v; hit.tri = ti;
-            best_inst = inst; best_prim = prim;
-        }
+        tri_eval(ti, v0, v1, v2, inst, prim);
     }
 
     // Scheduling pieces for a wave that batches node visits and triangle tests separately:
