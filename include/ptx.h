@@ -8,7 +8,7 @@
  * block binds it unchanged.  All structs are byte-identical
  * to /root/reference/src/shaders/shared.glsl:1-60.
  *
- * Conventions: every call returns a ptx_status (0 = ok) -- no exception or
+ * Conventions: every call returns a ptx_status code (0 = ok) -- no exception or
  * panic crosses the ABI; caller-owned inputs are copied before the call
  * returns; a context is not thread-safe, distinct contexts may be driven from
  * distinct threads; there is no CPU fallback (ptx_create fails without a HIP
@@ -149,7 +149,8 @@ int ptx_create_geometry(ptx_context *ctx, uint64_t first_vertex, uint64_t n_vert
                         uint64_t n_indices, uint32_t *geometry);
 
 /* The per-frame instance list + TLAS build of record_commands (renderer.rs:912-961).
- * Rebuilds the acceleration structure; marks the accumulation dirty. */
+ * Rebuilds the acceleration structure (synchronises the stream).  The caller restarts the
+ * accumulation (accumulated_count = 0), as renderer.rs:995-1000 does when the scene is dirty. */
 int ptx_set_instances(ptx_context *ctx, const ptx_instance *instances, uint32_t n);
 
 /* Renderer::resize_render_buffer (renderer.rs:583): reallocates the three images, resets accumulation. */

@@ -104,7 +104,7 @@ void Renderer::frame_uniforms(ptx_uniforms &u, ptx_camera &cam)
     u.z_near = z_near; u.z_far = z_far;
 }
 
-void Renderer::record_commands()
+bool Renderer::settle_state()
 {
     // renderer.rs:988-1000, short-circuit order kept: a moving camera leaves the scene flag set,
     // so the frame after the camera stops is dirty once more
@@ -115,7 +115,12 @@ void Renderer::record_commands()
     bool state_dirty = cam_dirty || scene.check_dirty_and_reset() || was_resized;
     if (scene.take_rebuild_flag()) sync_instances();
     if (state_dirty) accumulated_count = 0;
+    return state_dirty;
+}
 
+void Renderer::record_commands()
+{
+    bool state_dirty = settle_state();
     ptx_uniforms u; ptx_camera cam;
     frame_uniforms(u, cam);
     u.seed = next_seed();                                   // renderer.rs:1005,1021
@@ -126,21 +131,26 @@ void Renderer::record_commands()
 void Renderer::record_commands_batch(uint32_t n_frames)
 {
     if (!fixed_seed) throw std::runtime_error("record_commands_batch needs fixed_seed");
-    if (n_frames == 0) return;
-    record_commands();                                      // settles the dirty state like a normal frame
-    if (n_frames == 1) return;
-    // frames 2..n see a clean state: accumulated_count advances by one per frame up to the limit
-    uint32_t rest = n_frames - 1;
-    uint64_t room = accumulation_limit > accumulated_count ? (uint64_t)accumulation_limit - accumulated_count : 0;
-    uint32_t batched = (uint32_t)std::min<uint64_t>(rest, room);
-    if (batched) {
+    // Equivalent to n_frames record_commands() calls with camera and scene untouched in between:
+    // a dirty first frame renders with accumulated_count 0 and does not advance the counter; clean
+    // frames advance it by one each until accumulation_limit, after which every further frame
+    // re-renders at the limit.  Runs of clean, advancing frames go through one ptx_render_batch.
+    while (n_frames > 0) {
+        bool state_dirty = settle_state();
         ptx_uniforms u; ptx_camera cam;
         frame_uniforms(u, cam);
         u.seed = seed;
+        if (state_dirty || accumulated_count >= accumulation_limit) {
+            if (ptx_render(ctx_, &u, &cam, &params)) ptx_throw(ctx_, "trace_rays");
+            n_frames -= 1;
+            continue;
+        }
+        uint64_t room = (uint64_t)accumulation_limit - accumulated_count;
+        uint32_t batched = (uint32_t)std::min<uint64_t>(n_frames, room);
         if (ptx_render_batch(ctx_, &u, &cam, &params, batched)) ptx_throw(ctx_, "trace_rays");
         accumulated_count += batched;
+        n_frames -= batched;
     }
-    for (uint32_t i = batched; i < rest; ++i) record_commands();
 }
 
 std::vector<float> Renderer::read_image(int kind)

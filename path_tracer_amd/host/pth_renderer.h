@@ -65,6 +65,7 @@ public:
 
 private:
     void sync_instances();
+    bool settle_state();
     void frame_uniforms(ptx_uniforms &u, ptx_camera &cam);
     uint32_t next_seed();
     uint32_t render_resolution_[2] = {0, 0};

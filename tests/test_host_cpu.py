@@ -1,0 +1,193 @@
+"""CPU tests of the product's host side: the libraries load and export what include/ptx.h declares,
+no CPU fallback exists, codecs, host math, BVH builder + traversal logic, stand-in generator."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import ASSETS, ROOT, cornell, lion_boulder
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from path_tracer_amd import capi, host
+    header = open(os.path.join(ROOT, "include", "ptx.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char \*)\s*(ptx_[a-z_]+)\s*\(", header, re.M))
+    assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
+    L = capi.load()
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    H = host.load()
+    for name in host.EXPORTS:
+        assert hasattr(H, name), name
+
+
+def test_struct_layouts_match_the_reference_glsl():
+    from path_tracer_amd import capi
+    assert capi.VERTEX_DTYPE.itemsize == 48 and capi.VERTEX_DTYPE.fields["normal"][1] == 16 and capi.VERTEX_DTYPE.fields["uv"][1] == 32
+    assert capi.MATERIAL_DTYPE.itemsize == 32 and capi.MATERIAL_DTYPE.fields["roughness"][1] == 28
+    assert capi.OFFSETS_DTYPE.itemsize == 24 and capi.INSTANCE_DTYPE.itemsize == 76
+    assert C.sizeof(capi.Camera) == 192 and C.sizeof(capi.Uniforms) == 32 and C.sizeof(capi.RenderParams) == 32
+    p = capi.default_params()
+    assert (p.max_depth, p.rng_sample_offset) == (16, 0)
+    assert abs(p.t_min - 0.001) < 1e-9 and p.t_max == 10000.0 and abs(p.normal_eps - 0.001) < 1e-9   # rgen.glsl:18,37-38; rchit.glsl:242
+    l = capi.default_limits()
+    assert (l.max_vertices, l.max_indices, l.max_materials, l.max_offsets, l.max_textures) == (2500000, 5000000, 10000, 10000, 5000)
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from path_tracer_amd import capi, host
+    with pytest.raises(capi.PtxError) as e:
+        capi.Context(0)
+    assert e.value.code == capi.PTX_ERR_HIP
+    with pytest.raises(host.HostError):
+        host.Renderer(64, 64, 0)
+
+
+def test_image_codecs_against_pil(tmp_path):
+    from PIL import Image
+    from path_tracer_amd import host
+    for rel, tol in (("sponza/16275776544635328252.png", 0), ("sponza/white.png", 0),
+                     ("sponza/11474523244911310074.jpg", 3), ("lion_head_2k/textures/lion_head_diff_2k.jpg", 3)):
+        path = os.path.join(ASSETS, rel)
+        a = host.decode_image(path)
+        b = np.asarray(Image.open(path).convert("RGBA" if a.shape[2] == 4 else "RGB"))
+        d = np.abs(a.astype(int) - b.astype(int))
+        assert a.shape == b.shape and d.max() <= tol and d.mean() < 0.06, (rel, d.max(), d.mean())
+    rgb = np.random.default_rng(0).integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    out = str(tmp_path / "x.png")
+    host.encode_png_rgb8(out, rgb)
+    assert np.array_equal(np.asarray(Image.open(out)), rgb) and np.array_equal(host.decode_image(out), rgb)
+    with pytest.raises(host.HostError):
+        host.decode_image(os.path.join(ASSETS, "cornell", "cornell.bin"))
+
+
+def test_host_camera_matrices_equal_the_oracle(oracle):
+    from path_tracer_amd import host
+    for pos, yaw, fov, asp in (([0, 1.0, 3.9], 0, 40, 1.0), ([-8, 1.6, 0], -90, 70, 16 / 9), ([7, 2, 0], 90, 70, 16 / 9), ([2, 0.25, 0.6], 33, 55, 1.5)):
+        a = host.camera_matrices(pos, host.yaw_quat(yaw), np.deg2rad(np.float32(fov)), asp, 0.1, 1000.0)
+        b = oracle.camera_matrices(pos, oracle.yaw_quat(yaw), np.deg2rad(np.float32(fov)), asp, 0.1, 1000.0)
+        assert bytes(a) == bytes(b)
+
+
+@pytest.fixture(scope="module")
+def bvh_check():
+    """g++ build of the product's BVH builder + traversal headers for the host (test-only harness)."""
+    out = os.path.join(ROOT, "tests", "_build", "libbvh_check.so")
+    srcs = [os.path.join(ROOT, "tests", "native", "bvh_check.cpp"), os.path.join(ROOT, "path_tracer_amd", "csrc", "bvh_build.cpp")]
+    deps = srcs + [os.path.join(ROOT, "path_tracer_amd", "csrc", f) for f in ("traverse.h", "bvh8.h", "pt_math.h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread"] + srcs + ["-o", out])
+    L = C.CDLL(out)
+    L.bvhcheck_create.restype = C.c_void_p
+    L.bvhcheck_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+    L.bvhcheck_destroy.argtypes = [C.c_void_p]
+    L.bvhcheck_info.argtypes = [C.c_void_p] * 4
+    L.bvhcheck_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_float] + [C.c_void_p] * 5
+    return L
+
+
+def _world_tris(ing, oracle):
+    inst = ing.instances(oracle.transform_matrix)
+    vs, ids = [], []
+    for i, it in enumerate(inst):
+        off = it["off"]
+        idx = ing.indices[off["index_offset"]:off["index_offset"] + off["index_count"]].reshape(-1, 3)
+        p = ing.vertices["position"][off["vertex_offset"] + idx]
+        m = it["xform"]
+        w = np.empty_like(p)
+        for r in range(3):
+            w[..., r] = ((m[r, 0] * p[..., 0] + m[r, 1] * p[..., 1]) + m[r, 2] * p[..., 2]) + m[r, 3]
+        vs.append(w.reshape(-1, 9))
+        ids.append(np.stack([np.full(len(idx), i, np.uint32), np.arange(len(idx), dtype=np.uint32)], 1))
+    return np.ascontiguousarray(np.concatenate(vs), np.float32), np.ascontiguousarray(np.concatenate(ids), np.uint32)
+
+
+@pytest.mark.parametrize("scene,center,radius,n", [("cornell", (0, 1, 0), 1.0, 6000), ("lion", (0, 0.2, 0), 0.3, 1500)])
+def test_bvh8_traversal_equals_oracle_brute_force(oracle, bvh_check, scene, center, radius, n):
+    if scene == "cornell":
+        ing = cornell()
+    else:
+        from oracle.gltf_ingest import IngestedScene
+        ing = IngestedScene()
+        ing.import_gltf(os.path.join(ASSETS, "lion_head_2k/lion_head_2k.gltf"), decode_image=lambda p: np.zeros((4, 4, 4), np.uint8))
+    sc = oracle.scene_from_ingest(ing)
+    v, ids = _world_tris(ing, oracle)
+    h = bvh_check.bvhcheck_create(v.ctypes.data, ids.ctypes.data, len(v), 4)
+    rng = np.random.default_rng(1)
+    o = (rng.normal(size=(n, 3)) * radius + center).astype(np.float32)
+    d = ((rng.normal(size=(n, 3)) * radius * 0.5 + center).astype(np.float32) - o).astype(np.float32)
+    d[::97, 0] = 0.0                                  # axis-parallel rays
+    d[::89] *= 1e-3                                   # unnormalised directions
+    rays = np.ascontiguousarray(np.concatenate([o, d], 1), np.float32)
+    tuv = np.zeros((n, 3), np.float32); hid = np.zeros((n, 2), np.uint32)
+    ms = C.c_uint32()
+    bvh_check.bvhcheck_trace(h, rays.ctypes.data, n, 1e-3, 1e4, tuv.ctypes.data, hid.ctypes.data, None, None, C.byref(ms))
+    nodes, tris, depth = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    bvh_check.bvhcheck_info(h, C.byref(nodes), C.byref(tris), C.byref(depth))
+    assert tris.value == len(v) and ms.value < depth.value <= 32
+    hits = 0
+    for i in range(n):
+        r = sc.trace(o[i], d[i], flags=1)
+        if r is None:
+            assert hid[i, 0] == 0xFFFFFFFF
+        else:
+            hits += 1
+            assert (np.float32(r[0]), np.float32(r[1]), np.float32(r[2]), r[3], r[4]) == (tuv[i, 0], tuv[i, 1], tuv[i, 2], hid[i, 0], hid[i, 1])
+    assert hits > n // 10
+    bvh_check.bvhcheck_destroy(h)
+
+
+def test_bvh8_edge_cases(bvh_check):
+    def build(v):
+        v = np.ascontiguousarray(v, np.float32).reshape(-1, 9)
+        ids = np.stack([np.zeros(len(v), np.uint32), np.arange(len(v), dtype=np.uint32)], 1)
+        return bvh_check.bvhcheck_create(v.ctypes.data, np.ascontiguousarray(ids).ctypes.data, len(v), 1), len(v)
+
+    def trace(h, o, d):
+        rays = np.array([list(o) + list(d)], np.float32)
+        tuv = np.zeros((1, 3), np.float32); hid = np.zeros((1, 2), np.uint32)
+        bvh_check.bvhcheck_trace(h, rays.ctypes.data, 1, 1e-3, 1e4, tuv.ctypes.data, hid.ctypes.data, None, None, None)
+        return tuv[0], hid[0]
+
+    h, _ = build(np.zeros((0, 9)))                    # empty scene
+    assert trace(h, (0, 0, 0), (0, 0, -1))[1][0] == 0xFFFFFFFF
+    h, _ = build([[-1, -1, -2, 1, -1, -2, 0, 1, -2]])  # a single triangle: leaf root
+    t, i = trace(h, (0, 0, 0), (0, 0, -1))
+    assert t[0] == 2.0 and i[1] == 0
+    # many coincident triangles: equal t everywhere, lowest primitive wins; plus a non-finite one that is skipped
+    tri = [-1, -1, -2, 1, -1, -2, 0, 1, -2]
+    h, _ = build([tri] * 40 + [[np.nan] * 9])
+    t, i = trace(h, (0, 0, 0), (0, 0, -1))
+    assert t[0] == 2.0 and i[1] == 0
+    n = C.c_uint64(); tr = C.c_uint64(); dp = C.c_uint32()
+    bvh_check.bvhcheck_info(h, C.byref(n), C.byref(tr), C.byref(dp))
+    assert tr.value == 40
+
+
+def test_standins_are_deterministic_and_match_the_declared_layout(tmp_path):
+    import json
+    from path_tracer_amd import standins
+    a, b = str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
+    gltf = os.path.join(ASSETS, "sponza", "Sponza.gltf")
+    st = standins.make_sponza_bin(gltf, a)
+    standins.make_sponza_bin(gltf, b)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    doc = json.load(open(gltf))
+    assert os.path.getsize(a) == doc["buffers"][0]["byteLength"] == 9528220
+    assert st["triangles"] == 262267 and st["vertices"] == 192496 and st["degenerate"] < 0.05 * st["triangles"]
+    # every primitive stays inside its declared accessor AABB
+    from oracle.gltf_ingest import _accessor
+    buf = [open(a, "rb").read()]
+    for p in doc["meshes"][0]["primitives"]:
+        acc = doc["accessors"][p["attributes"]["POSITION"]]
+        pos = _accessor(doc, buf, p["attributes"]["POSITION"])
+        assert np.all(pos >= np.array(acc["min"], np.float32) - 1e-3) and np.all(pos <= np.array(acc["max"], np.float32) + 1e-3)
+        idx = _accessor(doc, buf, p["indices"])
+        assert idx.max() < acc["count"]

@@ -1,0 +1,62 @@
+"""The N > 1 path on CPU: two gloo ranks each render their slice of the sample budget (the oracle
+stands in for the GPU renderer -- same uniforms / rng_sample_offset contract as ptx_render_batch),
+the slices are combined by path_tracer_amd.multi_gpu.combine_accumulation, and the result must match
+a single-process render of the whole budget."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import ROOT, SEED, cornell, rel_mse
+
+TOTAL_SPP, W, H = 8, 48, 32
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as O
+    from path_tracer_amd.multi_gpu import combine_accumulation, partition_samples
+    first, n = partition_samples(TOTAL_SPP, world, rank)
+    sc = O.scene_from_ingest(cornell())
+    cam = O.camera_matrices([0, 1.0, 3.9], O.yaw_quat(0), np.deg2rad(np.float32(40)), W / H, 0.1, 1000.0)
+    # local running mean over this rank's samples: accumulated_count 0..n-1, RNG indices first..first+n-1
+    r = sc.render(cam, W, H, n, SEED, first_sample=0, params=O.default_params(rng_sample_offset=first), threads=2)
+    t = torch.from_numpy(r["albedo"].copy())
+    combined = combine_accumulation(t, dist, world, root=0)
+    if rank == 0:
+        np.save(out_path, combined.numpy())
+    else:
+        assert combined is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partition_samples():
+    from path_tracer_amd.multi_gpu import partition_samples
+    assert [partition_samples(1024, 8, r) for r in (0, 1, 7)] == [(0, 128), (128, 128), (896, 128)]
+    assert partition_samples(5, 1, 0) == (0, 5)
+    with pytest.raises(ValueError):
+        partition_samples(10, 4, 0)
+
+
+def test_two_rank_spp_partition_matches_single_process(oracle, tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "combined.npy")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    combined = np.load(out)
+    sc = oracle.scene_from_ingest(cornell())
+    cam = oracle.camera_matrices([0, 1.0, 3.9], oracle.yaw_quat(0), np.deg2rad(np.float32(40)), W / H, 0.1, 1000.0)
+    whole = sc.render(cam, W, H, TOTAL_SPP, SEED)["albedo"]
+    assert np.all(combined[..., 3] == 1.0)
+    # same samples, different fp32 summation order (running mean vs mean of partial means)
+    assert np.abs(combined - whole).max() < 2e-6
+    assert rel_mse(combined, whole) < 1e-10
