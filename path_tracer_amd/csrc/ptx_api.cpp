@@ -61,7 +61,7 @@ struct ptx_context {
 
     // wavefront state
     uint64_t path_capacity = 0;
-    uint64_t target_paths = 16u << 20;
+    uint64_t target_paths = 32u << 20;
     uint32_t extend_waves = 4096;           // persistent grid of the traversal kernel
     RayRec *d_rays[2] = {nullptr, nullptr};
     HitRec *d_hits = nullptr;

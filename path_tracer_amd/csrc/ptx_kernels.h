@@ -64,8 +64,11 @@ constexpr uint32_t kNextBase = kMaxDepthLimit + 2;      // counters[kNextBase + 
 constexpr uint32_t kNumCounters = 2 * kMaxDepthLimit + 3;
 
 // traversal stack: entries held in LDS per lane, remainder in private memory
-constexpr int kLdsStack = 8;
-constexpr int kOvfStack = 24;
+#ifndef PTX_LDS_STACK
+#define PTX_LDS_STACK 8
+#endif
+constexpr int kLdsStack = PTX_LDS_STACK;
+constexpr int kOvfStack = 32 - PTX_LDS_STACK;
 constexpr uint32_t kMaxBvhDepth = kLdsStack + kOvfStack;
 
 void launch_raygen(hipStream_t s, const FrameDev &f, uint32_t n_paths, RayRec *rays, uint32_t *counters);

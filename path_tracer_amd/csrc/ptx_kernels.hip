@@ -63,10 +63,24 @@ __global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, Ra
 }
 
 // ---------------------------------------------------------------- extend
-// Persistent waves with dynamic ray fetch: a wave keeps stepping its 64 traversal state machines
-// and, whenever kRefill or more lanes have finished, refills them from the bounce's ray queue with
-// one atomic per wave.  Path lengths through the BVH are heavy-tailed; without the refill a wave
-// runs at the pace of its slowest ray (11 % VALU lane utilisation measured, profiles/r01a).
+// Persistent one-wave workgroups walk the BVH with 64 independent per-lane state machines.
+//
+//  * Dynamic ray fetch: whenever `refill` or more lanes have finished, the wave refills them from
+//    the bounce's ray queue.  Path lengths through the BVH are heavy-tailed; without the refill a
+//    wave runs at the pace of its slowest ray (11 % VALU lane utilisation measured, profiles/r01a).
+//    Rays are handed out in two levels -- a wave reserves a chunk of the queue with one atomic and
+//    refills from that chunk -- because one atomic per refill on a single word saturates at
+//    ~88 M/s chip-wide (MI355X_MICROARCH.md "dequeue").
+//  * Wave-level triangle queue: a lane that hits leaves does not test their triangles itself (the
+//    triangle code would run for the ~20 of 64 lanes that happen to have one pending, r01e).  The
+//    triangles go to a per-wave FIFO in LDS as (triangle, owner lane) pairs and the owner carries
+//    on down the tree; when 64 pairs have collected, ANY lane tests ANY pair (ray fetched from
+//    the owner with ds_bpermute) and successful tests are handed back to their owners.  Closest
+//    hit with the (instance, primitive) tie-break is order-independent, so the image is unchanged;
+//    a ray is complete once its node walk is done and the FIFO head has passed its last pair.
+//  * Nodes are loaded straight into registers: with the queue the kernel is bound by the latency
+//    of its dependent chains, not by VALU issue or cache bandwidth (profiles/r01h notes), so what
+//    pays is occupancy -- 6 waves/SIMD at <= 80 VGPRs and 4.8 KB of LDS per wave.
 struct LaneStack {
     uint2 *lds;                 // this lane's column of the workgroup's LDS stack
     uint2 ovf[kOvfStack];
@@ -87,37 +101,43 @@ struct LaneStack {
     __device__ __forceinline__ bool empty() const { return sp == 0; }
 };
 
-
-// Asynchronous fetch of one 80-byte node per lane straight into LDS (gfx950 LDS-DMA,
-// global_load_lds_dwordx4: per-lane global address, destination = wave-uniform base + lane * 16;
-// no VGPRs are held while the load is in flight).  Lanes that do not call it are exec-masked.
-__device__ __forceinline__ void prefetch_node(const Bvh8Node *nodes, uint32_t ni, uint4 *slot)
-{
-    const uint4 *src = reinterpret_cast<const uint4 *>(nodes + ni);
-#pragma unroll
-    for (int k = 0; k < 5; ++k)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k),
-                                         (__attribute__((address_space(3))) void *)(slot + k * 64), 16, 0, 0);
-}
-
-struct ExtendSched { int refill, node_min, tri_min; uint32_t chunk; };   // lane-count thresholds (wave-uniform)
+// wave-uniform scheduling thresholds (lane counts) and the ray-fetch chunk
+struct ExtendSched { int refill, tri_min, flush_min; uint32_t chunk; };
 
 #ifndef PTX_EXTEND_WAVES_PER_EU
-#define PTX_EXTEND_WAVES_PER_EU 4
+#define PTX_EXTEND_WAVES_PER_EU 6
 #endif
+
+constexpr uint32_t kTriQueue = 128;   // entries, power of two
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // one wave per workgroup and DS operations of a wave complete in order: only the compiler
+    // needs to be kept from moving LDS traffic across this point
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float lane_read_f(float v, uint32_t src_lane)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
+}
+__device__ __forceinline__ uint32_t lane_read_u(uint32_t v, uint32_t src_lane)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
+}
 
 template <bool kStats>
 __global__ void __launch_bounds__(kExtendBlock) __attribute__((amdgpu_waves_per_eu(PTX_EXTEND_WAVES_PER_EU, PTX_EXTEND_WAVES_PER_EU)))
-k_extend(SceneDev sc, float t_min, float t_max,
-                                                          const RayRec *__restrict__ rays,
-                                                          const uint32_t *__restrict__ count,
-                                                          uint32_t *__restrict__ next,
-                                                          HitRec *__restrict__ hits,
-                                                          unsigned long long *__restrict__ trav_totals, ExtendSched sched)
+k_extend(SceneDev sc, float t_min, float t_max, const RayRec *__restrict__ rays, const uint32_t *__restrict__ count,
+           uint32_t *__restrict__ next, HitRec *__restrict__ hits, unsigned long long *__restrict__ trav_totals,
+           ExtendSched sched)
 {
     __shared__ uint2 s_stack[kLdsStack * kExtendBlock];
-    // per-lane landing slot of the node prefetch: piece k of lane L at s_node[k * 64 + L]
-    __shared__ uint4 s_node[kExtendBlock * 5];
+    __shared__ uint32_t s_qtri[kTriQueue];
+    __shared__ uint8_t s_qown[kTriQueue];
+    __shared__ uint8_t s_claim[kExtendBlock];
     const uint32_t n = *count;
     const uint32_t lane_id = threadIdx.x;
     LaneStack st;
@@ -125,17 +145,16 @@ k_extend(SceneDev sc, float t_min, float t_max,
     st.sp = 0;
     Traversal<LaneStack, kStats> tr;
     tr.ng_mask = 0; tr.tg_mask = 0;
-    bool active = false;        // this lane holds an unfinished ray
-    bool exhausted = false;     // wave-uniform: the queue has been handed out completely
+    tr.o = mk3(0.0f, 0.0f, 0.0f); tr.d = mk3(0.0f, 0.0f, 1.0f); tr.hit.t = 0.0f;
+    bool active = false;
+    bool exhausted = false;
     uint32_t ray = 0;
-    uint32_t next_ni = 0xFFFFFFFFu;   // node this lane visits next (already requested), 0xFFFFFFFF: none left
+    uint32_t next_ni = 0xFFFFFFFFu;
+    uint32_t q_head = 0, q_tail = 0;    // wave-uniform, monotone (mod 2^32)
+    uint32_t my_tail = 0;               // q_tail just after this lane's latest pair
     unsigned long long tot_nodes = 0, tot_tris = 0;
-    unsigned long long w_iters = 0, w_node_blocks = 0, w_node_lanes = 0, w_tri_blocks = 0, w_tri_lanes = 0, w_refills = 0;   // wave-level (kStats)
-
-    // Rays are handed out in two levels: a wave reserves a chunk of the queue with one atomic and
-    // refills its idle lanes from that chunk.  (One atomic per refill on a single word saturates
-    // at ~88 M/s chip-wide and was the bottleneck: MI355X_MICROARCH.md "dequeue".)
-    uint32_t chunk_next = 0, chunk_end = 0;          // wave-uniform
+    unsigned long long w_iters = 0, w_node_blocks = 0, w_node_lanes = 0, w_tri_blocks = 0, w_tri_lanes = 0, w_refills = 0;
+    uint32_t chunk_next = 0, chunk_end = 0;
     const uint32_t chunk = sched.chunk;
 
     for (;;) {
@@ -158,9 +177,9 @@ k_extend(SceneDev sc, float t_min, float t_max,
                     const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
                     float4 r0 = rp[0], r1 = rp[1];
                     bool go = tr.init(sc.n_nodes, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), t_min, t_max, st);
-                    next_ni = go ? tr.node_pick(st) : 0xFFFFFFFFu;      // the root
-                    if (go) prefetch_node(sc.nodes, next_ni, s_node);
+                    next_ni = go ? tr.node_pick(st) : 0xFFFFFFFFu;
                     ray = i;
+                    my_tail = q_head;
                     active = true;
                 }
                 uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -168,59 +187,104 @@ k_extend(SceneDev sc, float t_min, float t_max,
                 idle = __ballot(!active);
             }
         }
-        unsigned long long live = __ballot(active);
-        if (live == 0) {
+        if (__ballot(active) == 0) {
             if (exhausted) break;
             continue;
         }
-        // step until enough lanes have finished to make a refill worthwhile (or, once the queue
-        // is empty, until every lane is done)
         const int stop_at = exhausted ? 0 : (64 - sched.refill);
         do {
-            // Node visits and triangle tests are two long instruction streams; run each only when
-            // enough lanes want it (or nothing else can make progress), so neither executes for a
-            // handful of lanes while the rest of the wave idles.
-            // A lane visits a node when it has no triangle pending; its node was requested one
-            // step earlier (see prefetch_node) so the fetch overlapped the triangle tests.
-            bool want_node = active && tr.wants_node();
+            // ---- node visits: every lane whose walk is not finished and whose last leaf hits are queued
+            bool want_node = active && tr.tg_mask == 0 && next_ni != 0xFFFFFFFFu;
             const int nb = __popcll(__ballot(want_node));
-            const int tb = __popcll(__ballot(active && tr.wants_tri()));
-            const bool run_node = nb > 0 && (nb >= sched.node_min || tb < sched.tri_min);
-            if (kStats) { w_iters++; if (run_node) { w_node_blocks++; w_node_lanes += nb; } }
-            if (run_node) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // prefetched nodes have landed
+            if (kStats) { w_iters++; if (nb) { w_node_blocks++; w_node_lanes += nb; } }
+            if (nb > 0) {
                 if (want_node) {
-                    if (next_ni != 0xFFFFFFFFu) {
-                        Words80 nd;
-                        uint4 a = s_node[lane_id], b = s_node[64 + lane_id], c = s_node[128 + lane_id],
-                              d = s_node[192 + lane_id], e = s_node[256 + lane_id];
-                        nd.w[0] = a.x; nd.w[1] = a.y; nd.w[2] = a.z; nd.w[3] = a.w;
-                        nd.w[4] = b.x; nd.w[5] = b.y; nd.w[6] = b.z; nd.w[7] = b.w;
-                        nd.w[8] = c.x; nd.w[9] = c.y; nd.w[10] = c.z; nd.w[11] = c.w;
-                        nd.w[12] = d.x; nd.w[13] = d.y; nd.w[14] = d.z; nd.w[15] = d.w;
-                        nd.w[16] = e.x; nd.w[17] = e.y; nd.w[18] = e.z; nd.w[19] = e.w;
-                        tr.node_eval(nd);
-                        // the next node to visit is already determined: request it now
-                        next_ni = tr.next_group(st) ? tr.node_pick(st) : 0xFFFFFFFFu;
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slot fully read before it is refilled
-                        if (next_ni != 0xFFFFFFFFu) prefetch_node(sc.nodes, next_ni, s_node);
-                    } else {
-                        *reinterpret_cast<float4 *>(hits + ray) = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
-                        if (kStats) { tot_nodes += tr.stats.nodes; tot_tris += tr.stats.tris; }
-                        active = false;
+                    tr.node_eval(load_node(sc.nodes, next_ni));
+                    next_ni = tr.next_group(st) ? tr.node_pick(st) : 0xFFFFFFFFu;
+                }
+            }
+            // ---- queue the triangles of the leaves just hit, one per lane per round
+            {
+                uint32_t room = kTriQueue - (q_tail - q_head);
+                unsigned long long pend = __ballot(tr.tg_mask != 0);
+                while (pend != 0ull && room > 0u) {
+                    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
+                    uint32_t np = (uint32_t)__popcll(pend);
+                    uint32_t took = np < room ? np : room;
+                    bool mine = tr.tg_mask != 0 && rank < room;
+                    if (mine) {
+                        uint32_t ti = tr.tri_pick();
+                        uint32_t idx = (q_tail + rank) & (kTriQueue - 1u);
+                        s_qtri[idx] = ti;
+                        s_qown[idx] = (uint8_t)lane_id;
+                    }
+                    q_tail += took; room -= took;
+                    if (mine) my_tail = q_tail;
+                    pend = __ballot(tr.tg_mask != 0);
+                }
+            }
+            // ---- triangle tests, a full wave's worth at a time
+            {
+                const uint32_t qn = q_tail - q_head;
+                const bool walked = active && next_ni == 0xFFFFFFFFu && tr.tg_mask == 0;
+                const int n_wait = __popcll(__ballot(walked && (int)(q_head - my_tail) < 0));
+                const int n_node = __popcll(__ballot(active && tr.tg_mask == 0 && next_ni != 0xFFFFFFFFu));
+                if (qn >= (uint32_t)sched.tri_min || (qn > 0u && (n_wait >= sched.flush_min || n_node == 0))) {
+                    wave_lds_sync();
+                    const uint32_t nt = qn < 64u ? qn : 64u;
+                    if (kStats) { w_tri_blocks++; w_tri_lanes += nt; }
+                    const bool has = lane_id < nt;
+                    const uint32_t idx = (q_head + lane_id) & (kTriQueue - 1u);
+                    uint32_t ti = has ? s_qtri[idx] : 0u;
+                    uint32_t own = has ? (uint32_t)s_qown[idx] : lane_id;
+                    f3 o = mk3(lane_read_f(tr.o.x, own), lane_read_f(tr.o.y, own), lane_read_f(tr.o.z, own));
+                    f3 dd = mk3(lane_read_f(tr.d.x, own), lane_read_f(tr.d.y, own), lane_read_f(tr.d.z, own));
+                    float ht = lane_read_f(tr.hit.t, own);
+                    float t = 0.0f, u = 0.0f, v = 0.0f;
+                    bool cand = false;
+                    if (has) {
+                        const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + ti);
+                        float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
+                        cand = tri_test(o, dd, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), mk3(r2.x, r2.y, r2.z),
+                                        t_min, t_max, t, u, v) && t <= ht;
+                        if (kStats) tot_tris++;
+                    }
+                    q_head += nt;
+                    // hand the successful tests to their owners; two pairs of one owner take two rounds
+                    while (__ballot(cand) != 0ull) {
+                        s_claim[lane_id] = 0xFFu;
+                        wave_lds_sync();
+                        if (cand) s_claim[own] = (uint8_t)lane_id;
+                        wave_lds_sync();
+                        uint32_t src = s_claim[lane_id];
+                        bool won = cand && (uint32_t)s_claim[own] == lane_id;
+                        wave_lds_sync();
+                        float rt = lane_read_f(t, src & 63u), ru = lane_read_f(u, src & 63u), rv = lane_read_f(v, src & 63u);
+                        uint32_t rti = lane_read_u(ti, src & 63u);
+                        if (src != 0xFFu) {
+                            bool better = rt < tr.hit.t;
+                            if (rt == tr.hit.t) {
+                                // equal distance (shared edges, coincident surfaces): lowest (instance, primitive) wins
+                                const uint32_t *wa = reinterpret_cast<const uint32_t *>(sc.tris + rti);
+                                const uint32_t *wb = reinterpret_cast<const uint32_t *>(sc.tris + tr.hit.tri);
+                                uint32_t ia = wa[3], pa = wa[7], ib = wb[3], pb = wb[7];
+                                better = ia < ib || (ia == ib && pa < pb);
+                            }
+                            if (better) { tr.hit.t = rt; tr.hit.u = ru; tr.hit.v = rv; tr.hit.tri = rti; }
+                        }
+                        cand = cand && !won;
                     }
                 }
             }
-            bool want_tri = active && tr.wants_tri();
-            const int tb2 = __popcll(__ballot(want_tri));
-            if (tb2 > 0 && (!run_node || tb2 >= sched.tri_min)) {
-                if (kStats) { w_tri_blocks++; w_tri_lanes += tb2; }
-                if (want_tri) tr.tri_step(sc.tris);
+            // ---- rays whose walk is over and whose pairs have all been tested
+            if (active && next_ni == 0xFFFFFFFFu && tr.tg_mask == 0 && (int)(q_head - my_tail) >= 0) {
+                *reinterpret_cast<float4 *>(hits + ray) = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
+                if (kStats) tot_nodes += tr.stats.nodes;
+                active = false;
             }
         } while (__popcll(__ballot(active)) > stop_at);
     }
     if (kStats) {
-        // instrumented variant (ptx_set_profiling level 2): nodes fetched / triangles tested
         atomicAdd(&trav_totals[0], tot_nodes);
         atomicAdd(&trav_totals[1], tot_tris);
         if (threadIdx.x == 0) {
@@ -427,29 +491,32 @@ void launch_raygen(hipStream_t s, const FrameDev &f, uint32_t n_paths, RayRec *r
     hipLaunchKernelGGL(k_raygen, dim3(blocks ? blocks : 1u), dim3(256), 0, s, f, n_paths, rays, counters);
 }
 
-void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, const RayRec *rays, const uint32_t *count,
-                   uint32_t *next, uint32_t capacity, uint32_t max_waves, HitRec *hits, uint64_t *trav_totals)
+static const ExtendSched &extend_sched()
 {
-    static const ExtendSched refill = [] {
+    static const ExtendSched sched = [] {
         auto knob = [](const char *name, int dflt) { const char *e = getenv(name); int v = e ? atoi(e) : dflt; return v < 1 ? 1 : (v > 64 ? 64 : v); };
-        ExtendSched k; k.refill = knob("PTX_REFILL", 8); k.node_min = knob("PTX_NODE_MIN", 1); k.tri_min = knob("PTX_TRI_MIN", 1);
+        ExtendSched k; k.refill = knob("PTX_REFILL", 8); k.tri_min = knob("PTX_TRI_MIN", 64); k.flush_min = knob("PTX_FLUSH_MIN", 8);
         const char *ce = getenv("PTX_CHUNK"); int cv = ce ? atoi(ce) : 128; k.chunk = (uint32_t)(cv < 64 ? 64 : cv);
         return k;
     }();
+    return sched;
+}
+
+void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, const RayRec *rays, const uint32_t *count,
+                   uint32_t *next, uint32_t capacity, uint32_t max_waves, HitRec *hits, uint64_t *trav_totals)
+{
+    const ExtendSched &sched = extend_sched();
     uint32_t blocks = std::min((capacity + kExtendBlock - 1u) / kExtendBlock, max_waves);
     if (!blocks) return;
-    if (trav_totals)
-        hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, next,
-                           hits, reinterpret_cast<unsigned long long *>(trav_totals), refill);
-    else
-        hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, next,
-                           hits, (unsigned long long *)nullptr, refill);
+    unsigned long long *tt = reinterpret_cast<unsigned long long *>(trav_totals);
+    if (tt) hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, next, hits, tt, sched);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, next, hits, tt, sched);
 }
 
 uint32_t extend_resident_waves(int device)
 {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend<false>, kExtendBlock, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend<false>, kExtendBlock, 0) != hipSuccess || per_cu <= 0) per_cu = 24;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
     return (uint32_t)per_cu * (uint32_t)cus;
 }
