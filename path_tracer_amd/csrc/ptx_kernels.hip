@@ -119,6 +119,20 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Inclusive prefix sum over the 64 lanes: four row_shr steps inside each row of 16, then the two
+// row broadcasts of gfx9 DPP.
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
+{
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2 and 3
+    return (uint32_t)x;
+}
+
 __device__ __forceinline__ float lane_read_f(float v, uint32_t src_lane)
 {
     return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
@@ -146,6 +160,7 @@ k_extend(SceneDev sc, float t_min, float t_max, const RayRec *__restrict__ rays,
     Traversal<LaneStack, kStats> tr;
     tr.ng_mask = 0; tr.tg_mask = 0;
     tr.o = mk3(0.0f, 0.0f, 0.0f); tr.d = mk3(0.0f, 0.0f, 1.0f); tr.hit.t = 0.0f;
+    tr.t_min = t_min; tr.t_max = t_max;     // wave-uniform: keeps them out of the VGPRs
     bool active = false;
     bool exhausted = false;
     uint32_t ray = 0;
@@ -203,25 +218,29 @@ k_extend(SceneDev sc, float t_min, float t_max, const RayRec *__restrict__ rays,
                     next_ni = tr.next_group(st) ? tr.node_pick(st) : 0xFFFFFFFFu;
                 }
             }
-            // ---- queue the triangles of the leaves just hit, one per lane per round
-            {
-                uint32_t room = kTriQueue - (q_tail - q_head);
-                unsigned long long pend = __ballot(tr.tg_mask != 0);
-                while (pend != 0ull && room > 0u) {
-                    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
-                    uint32_t np = (uint32_t)__popcll(pend);
-                    uint32_t took = np < room ? np : room;
-                    bool mine = tr.tg_mask != 0 && rank < room;
-                    if (mine) {
+            // ---- queue the triangles of the leaves just hit: wave prefix sum of the per-lane counts
+            //      (six DPP adds), then every lane writes its own run of the FIFO
+            if (__ballot(tr.tg_mask != 0) != 0ull) {
+                const uint32_t room = kTriQueue - (q_tail - q_head);
+                const uint32_t cnt = (uint32_t)__popc(tr.tg_mask);
+                const uint32_t incl = wave_inclusive_sum(cnt);
+                // lanes whose whole group fits form a prefix (incl is monotone); the others keep
+                // their group and stay out of the node block until the FIFO has drained
+                const bool fits = incl <= room;
+                const uint32_t n_fit = (uint32_t)__popcll(__ballot(fits));
+                const uint32_t total = n_fit ? (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)n_fit - 1) : 0u;
+                if (fits && cnt) {
+                    uint32_t pos = q_tail + incl - cnt;
+                    my_tail = q_tail + incl;
+                    do {
                         uint32_t ti = tr.tri_pick();
-                        uint32_t idx = (q_tail + rank) & (kTriQueue - 1u);
+                        uint32_t idx = pos & (kTriQueue - 1u);
                         s_qtri[idx] = ti;
                         s_qown[idx] = (uint8_t)lane_id;
-                    }
-                    q_tail += took; room -= took;
-                    if (mine) my_tail = q_tail;
-                    pend = __ballot(tr.tg_mask != 0);
+                        ++pos;
+                    } while (tr.tg_mask != 0);
                 }
+                q_tail += total;
             }
             // ---- triangle tests, a full wave's worth at a time
             {
