@@ -81,22 +81,28 @@ __global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, Ra
 //  * Nodes are loaded straight into registers: with the queue the kernel is bound by the latency
 //    of its dependent chains, not by VALU issue or cache bandwidth (profiles/r01h notes), so what
 //    pays is occupancy -- 6 waves/SIMD at <= 80 VGPRs and 4.8 KB of LDS per wave.
+// Traversal stack of one lane: the first kLdsStack entries in the wave's LDS block (column
+// `lane`), the rest in a private array.  The private array is referenced through a pointer so that
+// `sp` and the LDS column stay in registers (a struct holding the array itself is demoted to
+// scratch as a whole, stack pointer included).
+typedef __attribute__((address_space(3))) uint2 lds_uint2;
+typedef __attribute__((address_space(5))) uint2 prv_uint2;
 struct LaneStack {
-    uint2 *lds;                 // this lane's column of the workgroup's LDS stack
-    uint2 ovf[kOvfStack];
+    lds_uint2 *lds;             // this lane's column of the workgroup's LDS stack
+    prv_uint2 *ovf;             // kOvfStack private entries
     int sp;
     __device__ __forceinline__ void clear() { sp = 0; }
     __device__ __forceinline__ void push(uint32_t base, uint32_t mask)
     {
-        if (sp < kLdsStack) lds[sp * kExtendBlock] = make_uint2(base, mask);
-        else ovf[sp - kLdsStack] = make_uint2(base, mask);
+        if (sp < kLdsStack) { lds[sp * kExtendBlock].x = base; lds[sp * kExtendBlock].y = mask; }
+        else { ovf[sp - kLdsStack].x = base; ovf[sp - kLdsStack].y = mask; }
         ++sp;
     }
     __device__ __forceinline__ void pop(uint32_t &base, uint32_t &mask)
     {
         --sp;
-        uint2 v = (sp < kLdsStack) ? lds[sp * kExtendBlock] : ovf[sp - kLdsStack];
-        base = v.x; mask = v.y;
+        if (sp < kLdsStack) { base = lds[sp * kExtendBlock].x; mask = lds[sp * kExtendBlock].y; }
+        else { base = ovf[sp - kLdsStack].x; mask = ovf[sp - kLdsStack].y; }
     }
     __device__ __forceinline__ bool empty() const { return sp == 0; }
 };
@@ -154,8 +160,10 @@ k_extend(SceneDev sc, float t_min, float t_max, const RayRec *__restrict__ rays,
     __shared__ uint8_t s_claim[kExtendBlock];
     const uint32_t n = *count;
     const uint32_t lane_id = threadIdx.x;
+    uint2 ovf_store[kOvfStack];
     LaneStack st;
-    st.lds = s_stack + threadIdx.x;
+    st.lds = (lds_uint2 *)s_stack + threadIdx.x;
+    st.ovf = (prv_uint2 *)ovf_store;
     st.sp = 0;
     Traversal<LaneStack, kStats> tr;
     tr.ng_mask = 0; tr.tg_mask = 0;
