@@ -165,6 +165,37 @@ PT_HD bool tri_test(f3 o, f3 d, f3 v0, f3 v1, f3 v2, float t_min, float t_max, f
     return true;
 }
 
+// (u, v) of an accepted hit, by the same expression tree as tri_test: the traversal kernel keeps
+// only (t, triangle) per ray and the shading stage recomputes the barycentrics once per ray
+// instead of dividing in every triangle test.
+PT_HD void tri_uv(f3 o, f3 d, f3 v0, f3 v1, f3 v2, float &u_out, float &v_out)
+{
+    f3 A = v0 - o, B = v1 - o, C = v2 - o;
+    float U = dot(d, cross(C - B, C + B));
+    float V = dot(d, cross(A - C, A + C));
+    float W = dot(d, cross(B - A, B + A));
+    float det = (U + V) + W;
+    u_out = V / det; v_out = W / det;
+}
+
+// tri_test without the barycentrics (same U, V, W, det, t and the same accept / reject decisions)
+PT_HD bool tri_test_t(f3 o, f3 d, f3 v0, f3 v1, f3 v2, float t_min, float t_max, float &t_out)
+{
+    f3 A = v0 - o, B = v1 - o, C = v2 - o;
+    float U = dot(d, cross(C - B, C + B));
+    float V = dot(d, cross(A - C, A + C));
+    float W = dot(d, cross(B - A, B + A));
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    float det = (U + V) + W;
+    if (det == 0.0f) return false;
+    f3 Ng = cross(B - A, C - A);
+    float den = dot(d, Ng);
+    float t = dot(A, Ng) / den;
+    if (!(t > t_min && t < t_max)) return false;
+    t_out = t;
+    return true;
+}
+
 // closest hit; equal t -> lowest (instance, primitive)
 PT_HD bool hit_better(float t, uint32_t inst, uint32_t prim, float bt, uint32_t bi, uint32_t bp)
 {

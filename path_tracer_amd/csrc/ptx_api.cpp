@@ -63,8 +63,8 @@ struct ptx_context {
     uint64_t path_capacity = 0;
     uint64_t target_paths = 32u << 20;
     uint32_t extend_waves = 4096;           // persistent grid of the traversal kernel
-    RayRec *d_rays[2] = {nullptr, nullptr};
-    HitRec *d_hits = nullptr;
+    void *d_rays[2] = {nullptr, nullptr};   // two ray queues (three 16-byte planes each), ping-pong per bounce
+    HitOut *d_hits = nullptr;
     float4 *d_results = nullptr;
     uint32_t *d_counters = nullptr;
     uint64_t *d_totals = nullptr;           // rays, hits, samples, nodes fetched, triangles tested
@@ -111,9 +111,9 @@ int ensure_paths(ptx_context *c, uint64_t n)
 {
     if (n <= c->path_capacity) return PTX_OK;
     free_paths(c);
-    HIP_TRY(c, hipMalloc((void **)&c->d_rays[0], n * sizeof(RayRec)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_rays[1], n * sizeof(RayRec)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_hits, n * sizeof(HitRec)));
+    HIP_TRY(c, hipMalloc(&c->d_rays[0], n * kRayBytes));
+    HIP_TRY(c, hipMalloc(&c->d_rays[1], n * kRayBytes));
+    HIP_TRY(c, hipMalloc((void **)&c->d_hits, n * sizeof(HitOut)));
     HIP_TRY(c, hipMalloc((void **)&c->d_results, n * sizeof(float4)));
     c->path_capacity = n;
     return PTX_OK;
@@ -376,6 +376,9 @@ int ptx_set_instances(ptx_context *c, const ptx_instance *inst, uint32_t n)
         memcpy(tr.v0, &wv[(uint64_t)t * 9], 12); memcpy(tr.v1, &wv[(uint64_t)t * 9 + 3], 12); memcpy(tr.v2, &wv[(uint64_t)t * 9 + 6], 12);
         tr.instance = tri_inst[t]; tr.prim = tri_prim[t]; tr.material = in.off.material_offset;
         ShadeRec &sr = shade[k];
+        memset(&sr, 0, sizeof sr);
+        memcpy(sr.v0, tr.v0, 12); memcpy(sr.v1, tr.v1, 12); memcpy(sr.v2, tr.v2, 12);
+        sr.instance = tr.instance; sr.prim = tr.prim;
         memcpy(sr.n0, a.normal, 12); memcpy(sr.n1, b.normal, 12); memcpy(sr.n2, d.normal, 12);   // object space, as the reference
         memcpy(sr.uv0, a.uv, 8); memcpy(sr.uv1, b.uv, 8); memcpy(sr.uv2, d.uv, 8);
         sr.material = in.off.material_offset;
@@ -475,9 +478,9 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
         uint32_t n_paths = (uint32_t)(ns * npix);
         f.mean_base = u->accumulated_count + s0;
         f.ids_sample = (s0 == 0) ? 0u : 0xFFFFFFFFu;
-        launch_raygen(c->stream, f, n_paths, c->d_rays[0], c->d_counters);
+        launch_raygen(c->stream, f, n_paths, make_ray_queue(c->d_rays[0], c->path_capacity), c->d_counters);
         for (uint32_t b = 0; b < bounces; ++b) {
-            RayRec *rin = c->d_rays[b & 1], *rout = c->d_rays[(b & 1) ^ 1];
+            RayQueue rin = make_ray_queue(c->d_rays[b & 1], c->path_capacity), rout = make_ray_queue(c->d_rays[(b & 1) ^ 1], c->path_capacity);
             if (c->profiling) {
                 EventPair e = get_events(c, 0);
                 HIP_TRY(c, hipEventRecord(e.a, c->stream));

@@ -10,23 +10,42 @@
 
 namespace ptx {
 
-// One in-flight path segment, 48 B = three 16-byte loads/stores, queue order.
-struct alignas(16) RayRec {
-    float ox, oy, oz; uint32_t path;        // path = sample_in_chunk * n_pixels + pixel
-    float dx, dy, dz; uint32_t uv_state;    // hash2(floatBitsToUint(in_uv)), constant per pixel
-    float tx, ty, tz; uint32_t _pad;        // running product of attenuations (rgen.glsl:80)
+// The ray queue of one bounce, structure-of-arrays: three planes of 16-byte elements so that a
+// wave's loads and stores are contiguous kilobytes (a 48-byte record per ray made every store a
+// partial line write: 2x write traffic in the shading stage, profiles/r01h notes).
+//   plane 0: origin.xyz, path          path = sample_in_chunk * n_pixels + pixel
+//   plane 1: direction.xyz, uv_state   uv_state = hash2(floatBitsToUint(in_uv)), constant per pixel
+//   plane 2: throughput.xyz, unused    running product of attenuations (rgen.glsl:80)
+struct RayQueue {
+    float4 *org, *dir, *thr;
 };
-static_assert(sizeof(RayRec) == 48, "RayRec must be 48 bytes");
+constexpr uint32_t kRayBytes = 48;      // per ray over the three planes
+inline RayQueue make_ray_queue(void *base, uint64_t capacity)
+{
+    RayQueue q; q.org = (float4 *)base; q.dir = q.org + capacity; q.thr = q.dir + capacity;
+    return q;
+}
 
-// Per-triangle shading inputs in leaf order, 64 B = four 16-byte loads: what rchit.glsl:160-190
-// gathers through Offsets -> indices -> 3 x Vertex -> material_offset, pre-joined at
-// ptx_set_instances time.
-struct alignas(16) ShadeRec {
+// Result of the closest-hit query of one ray, 8 B: the shading stage recomputes (u, v) from it.
+struct alignas(8) HitOut {
+    float t;
+    uint32_t tri;    // index into the leaf-ordered TriRec array; 0xFFFFFFFF = miss
+};
+static_assert(sizeof(HitOut) == 8, "HitOut must be 8 bytes");
+
+// Per-triangle shading inputs in leaf order: what rchit.glsl:160-190 gathers through Offsets ->
+// indices -> 3 x Vertex -> material_offset, pre-joined at ptx_set_instances time, plus the
+// world-space positions (for the barycentrics) and the ids.  One 128-byte record = one L2 line
+// per shaded hit.
+struct alignas(128) ShadeRec {
+    float v0[3]; uint32_t instance;
+    float v1[3]; uint32_t prim;
+    float v2[3]; uint32_t material;
     float n0[3], n1[3], n2[3];
     float uv0[2], uv1[2], uv2[2];
-    uint32_t material;
+    uint32_t _pad[5];
 };
-static_assert(sizeof(ShadeRec) == 64, "ShadeRec must be 64 bytes");
+static_assert(sizeof(ShadeRec) == 128, "ShadeRec must be 128 bytes");
 
 struct TexDesc {
     const uint8_t *texels;   // RGBA8, row 0 first
@@ -71,14 +90,14 @@ constexpr int kLdsStack = PTX_LDS_STACK;
 constexpr int kOvfStack = 32 - PTX_LDS_STACK;
 constexpr uint32_t kMaxBvhDepth = kLdsStack + kOvfStack;
 
-void launch_raygen(hipStream_t s, const FrameDev &f, uint32_t n_paths, RayRec *rays, uint32_t *counters);
+void launch_raygen(hipStream_t s, const FrameDev &f, uint32_t n_paths, RayQueue rays, uint32_t *counters);
 // `next`: the bounce's fetch cursor (zeroed by raygen); `max_waves`: resident-wave budget of the persistent grid
-void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, const RayRec *rays, const uint32_t *count,
-                   uint32_t *next, uint32_t capacity, uint32_t max_waves, HitRec *hits,
+void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, RayQueue rays, const uint32_t *count,
+                   uint32_t *next, uint32_t capacity, uint32_t max_waves, HitOut *hits,
                    uint64_t *trav_totals /* NULL: uninstrumented */);
 uint32_t extend_resident_waves(int device);
 void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
-                  const RayRec *rays_in, const HitRec *hits, uint32_t *counters, uint32_t capacity, RayRec *rays_out,
+                  RayQueue rays_in, const HitOut *hits, uint32_t *counters, uint32_t capacity, RayQueue rays_out,
                   float4 *results);
 void launch_resolve(hipStream_t s, const FrameDev &f, const ImagesDev &img, const float4 *results, uint32_t n_samples);
 void launch_accumulate_stats(hipStream_t s, const uint32_t *counters, uint32_t max_depth, uint64_t n_samples,

@@ -22,7 +22,10 @@ namespace ptx {
 namespace {
 
 constexpr int kExtendBlock = 64;    // one wave per workgroup: resources free as soon as the wave retires
-constexpr int kShadeBlock = 1024;   // one queue-tail atomic per 1024 rays: a single word takes only ~88 M atomics/s
+#ifndef PTX_SHADE_BLOCK
+#define PTX_SHADE_BLOCK 1024
+#endif
+constexpr int kShadeBlock = PTX_SHADE_BLOCK;   // one queue-tail atomic per 1024 rays: a single word takes only ~88 M atomics/s
 
 __device__ __forceinline__ f3 mat4_mul(const float *m, float x, float y, float z, float w)
 {
@@ -35,7 +38,7 @@ __device__ __forceinline__ f3 mat4_mul(const float *m, float x, float y, float z
 }
 
 // ---------------------------------------------------------------- raygen
-__global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, RayRec *__restrict__ rays,
+__global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, RayQueue rays,
                                                 uint32_t *__restrict__ counters)
 {
     uint32_t p = blockIdx.x * 256u + threadIdx.x;
@@ -56,10 +59,9 @@ __global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, Ra
     f3 tn = normalize(target);
     f3 dir = normalize(mat4_mul(f.cam.view_inverse, tn.x, tn.y, tn.z, 0.0f));
 
-    float4 *out = reinterpret_cast<float4 *>(rays + p);
-    out[0] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(p));
-    out[1] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(hash2(f2u(uvx), f2u(uvy))));
-    out[2] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);   // rgen.glsl:62
+    rays.org[p] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(p));
+    rays.dir[p] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(hash2(f2u(uvx), f2u(uvy))));
+    rays.thr[p] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);   // rgen.glsl:62
 }
 
 // ---------------------------------------------------------------- extend
@@ -80,7 +82,8 @@ __global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, Ra
 //    a ray is complete once its node walk is done and the FIFO head has passed its last pair.
 //  * Nodes are loaded straight into registers: with the queue the kernel is bound by the latency
 //    of its dependent chains, not by VALU issue or cache bandwidth (profiles/r01h notes), so what
-//    pays is occupancy -- 6 waves/SIMD at <= 80 VGPRs and 4.8 KB of LDS per wave.
+//    pays is occupancy without spills -- 5 waves/SIMD at <= 96 VGPRs (6 waves spill, 7 % slower) and
+//    4.8 KB of LDS per wave.
 // Traversal stack of one lane: the first kLdsStack entries in the wave's LDS block (column
 // `lane`), the rest in a private array.  The private array is referenced through a pointer so that
 // `sp` and the LDS column stay in registers (a struct holding the array itself is demoted to
@@ -111,7 +114,7 @@ struct LaneStack {
 struct ExtendSched { int refill, tri_min, flush_min; uint32_t chunk; };
 
 #ifndef PTX_EXTEND_WAVES_PER_EU
-#define PTX_EXTEND_WAVES_PER_EU 6
+#define PTX_EXTEND_WAVES_PER_EU 7
 #endif
 
 constexpr uint32_t kTriQueue = 128;   // entries, power of two
@@ -150,8 +153,8 @@ __device__ __forceinline__ uint32_t lane_read_u(uint32_t v, uint32_t src_lane)
 
 template <bool kStats>
 __global__ void __launch_bounds__(kExtendBlock) __attribute__((amdgpu_waves_per_eu(PTX_EXTEND_WAVES_PER_EU, PTX_EXTEND_WAVES_PER_EU)))
-k_extend(SceneDev sc, float t_min, float t_max, const RayRec *__restrict__ rays, const uint32_t *__restrict__ count,
-           uint32_t *__restrict__ next, HitRec *__restrict__ hits, unsigned long long *__restrict__ trav_totals,
+k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *__restrict__ count,
+           uint32_t *__restrict__ next, HitOut *__restrict__ hits, unsigned long long *__restrict__ trav_totals,
            ExtendSched sched)
 {
     __shared__ uint2 s_stack[kLdsStack * kExtendBlock];
@@ -197,8 +200,7 @@ k_extend(SceneDev sc, float t_min, float t_max, const RayRec *__restrict__ rays,
                 uint32_t avail = chunk_end - chunk_next;
                 if (!active && rank < avail) {
                     uint32_t i = chunk_next + rank;
-                    const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
-                    float4 r0 = rp[0], r1 = rp[1];
+                    float4 r0 = rays.org[i], r1 = rays.dir[i];
                     bool go = tr.init(sc.n_nodes, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), t_min, t_max, st);
                     next_ni = go ? tr.node_pick(st) : 0xFFFFFFFFu;
                     ray = i;
@@ -264,16 +266,20 @@ k_extend(SceneDev sc, float t_min, float t_max, const RayRec *__restrict__ rays,
                     const uint32_t idx = (q_head + lane_id) & (kTriQueue - 1u);
                     uint32_t ti = has ? s_qtri[idx] : 0u;
                     uint32_t own = has ? (uint32_t)s_qown[idx] : lane_id;
+                    // the owner's ray: origin and current closest t from its registers, direction
+                    // from the ray queue (not kept in registers: the node walk only needs 1/d)
                     f3 o = mk3(lane_read_f(tr.o.x, own), lane_read_f(tr.o.y, own), lane_read_f(tr.o.z, own));
-                    f3 dd = mk3(lane_read_f(tr.d.x, own), lane_read_f(tr.d.y, own), lane_read_f(tr.d.z, own));
                     float ht = lane_read_f(tr.hit.t, own);
-                    float t = 0.0f, u = 0.0f, v = 0.0f;
+                    uint32_t oray = lane_read_u(ray, own);
+                    float t = 0.0f;
                     bool cand = false;
                     if (has) {
+                        const float *dp = reinterpret_cast<const float *>(rays.dir + oray);
+                        f3 dd = mk3(dp[0], dp[1], dp[2]);
                         const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + ti);
                         float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
-                        cand = tri_test(o, dd, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), mk3(r2.x, r2.y, r2.z),
-                                        t_min, t_max, t, u, v) && t <= ht;
+                        cand = tri_test_t(o, dd, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), mk3(r2.x, r2.y, r2.z),
+                                          t_min, t_max, t) && t <= ht;
                         if (kStats) tot_tris++;
                     }
                     q_head += nt;
@@ -286,7 +292,7 @@ k_extend(SceneDev sc, float t_min, float t_max, const RayRec *__restrict__ rays,
                         uint32_t src = s_claim[lane_id];
                         bool won = cand && (uint32_t)s_claim[own] == lane_id;
                         wave_lds_sync();
-                        float rt = lane_read_f(t, src & 63u), ru = lane_read_f(u, src & 63u), rv = lane_read_f(v, src & 63u);
+                        float rt = lane_read_f(t, src & 63u);
                         uint32_t rti = lane_read_u(ti, src & 63u);
                         if (src != 0xFFu) {
                             bool better = rt < tr.hit.t;
@@ -297,7 +303,7 @@ k_extend(SceneDev sc, float t_min, float t_max, const RayRec *__restrict__ rays,
                                 uint32_t ia = wa[3], pa = wa[7], ib = wb[3], pb = wb[7];
                                 better = ia < ib || (ia == ib && pa < pb);
                             }
-                            if (better) { tr.hit.t = rt; tr.hit.u = ru; tr.hit.v = rv; tr.hit.tri = rti; }
+                            if (better) { tr.hit.t = rt; tr.hit.tri = rti; }
                         }
                         cand = cand && !won;
                     }
@@ -305,7 +311,7 @@ k_extend(SceneDev sc, float t_min, float t_max, const RayRec *__restrict__ rays,
             }
             // ---- rays whose walk is over and whose pairs have all been tested
             if (active && next_ni == 0xFFFFFFFFu && tr.tg_mask == 0 && (int)(q_head - my_tail) >= 0) {
-                *reinterpret_cast<float4 *>(hits + ray) = make_float4(tr.hit.t, tr.hit.u, tr.hit.v, __uint_as_float(tr.hit.tri));
+                *reinterpret_cast<float2 *>(hits + ray) = make_float2(tr.hit.t, __uint_as_float(tr.hit.tri));
                 if (kStats) tot_nodes += tr.stats.nodes;
                 active = false;
             }
@@ -338,10 +344,10 @@ __device__ __forceinline__ f3 sample_texture(const TexDesc &tx, const float *lut
 }
 
 __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, ImagesDev img, uint32_t depth,
-                                                        const RayRec *__restrict__ rays_in,
-                                                        const HitRec *__restrict__ hits,
+                                                        RayQueue rays_in,
+                                                        const HitOut *__restrict__ hits,
                                                         uint32_t *__restrict__ counters,
-                                                        RayRec *__restrict__ rays_out, float4 *__restrict__ results)
+                                                        RayQueue rays_out, float4 *__restrict__ results)
 {
     __shared__ float s_lut[256];
     __shared__ uint32_t s_wave_live[kShadeBlock / 64], s_wave_hits[kShadeBlock / 64];
@@ -354,14 +360,13 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
     bool alive = false, was_hit = false;
     float4 o0, o1, o2;
     if (valid) {
-        const float4 *rp = reinterpret_cast<const float4 *>(rays_in + i);
-        float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-        float4 hr = *reinterpret_cast<const float4 *>(hits + i);
+        float4 r0 = rays_in.org[i], r1 = rays_in.dir[i], r2 = rays_in.thr[i];
+        float2 hr = *reinterpret_cast<const float2 *>(hits + i);
         f3 ro = mk3(r0.x, r0.y, r0.z), rd = mk3(r1.x, r1.y, r1.z);
         uint32_t path = __float_as_uint(r0.w), uv_state = __float_as_uint(r1.w);
         uint32_t sample = path / f.n_pixels, pix = path - sample * f.n_pixels;
         uint32_t acc = f.mean_base + sample;            // uniforms.accumulated_count of this path's frame
-        uint32_t tri = __float_as_uint(hr.w);
+        uint32_t tri = __float_as_uint(hr.y);
 
         f3 att, normal, new_o = ro, new_d = rd;
         float dist;
@@ -377,14 +382,17 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
             was_hit = true;
             // rchit.glsl:160-183
             const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri);
-            float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+            float4 t0 = sp[0], t1 = sp[1], t2 = sp[2], s0 = sp[3], s1 = sp[4], s2 = sp[5], s3 = sp[6];
             f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
-            float bx = 1.0f - hr.y - hr.z, by = hr.y, bz = hr.z;
+            // barycentrics of the hit, recomputed from the triangle (tri_uv == tri_test's u, v)
+            float hu, hv;
+            tri_uv(ro, rd, mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), hu, hv);
+            float bx = 1.0f - hu - hv, by = hu, bz = hv;
             normal = normalize((n0 * bx + n1 * by) + n2 * bz);
             float tu = (s2.y * bx + s2.w * by) + s3.y * bz;
             float tv = (s2.z * bx + s3.x * by) + s3.z * bz;
             f3 world_pos = ro + rd * hr.x;                                   // :186
-            uint32_t mi = __float_as_uint(s3.w);
+            uint32_t mi = __float_as_uint(t2.w);
             const float4 *mp = reinterpret_cast<const float4 *>(sc.materials + mi);
             float4 m0 = mp[0], m1 = mp[1];                                   // :190
             f3 albedo;
@@ -410,8 +418,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
             new_d = scatter;
             dist = length(new_o - ro);                                       // :254
             if (depth == 0 && sample == f.ids_sample) {
-                const uint32_t *tw = reinterpret_cast<const uint32_t *>(sc.tris + tri);
-                id_inst = tw[3]; id_prim = tw[7];
+                id_inst = __float_as_uint(t0.w); id_prim = __float_as_uint(t1.w);
             }
         }
         f3 thr = mk3(r2.x, r2.y, r2.z) * att;                                // rgen.glsl:80
@@ -466,8 +473,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
     if (alive) {
         uint32_t before = wave ? s_wave_live[wave - 1] : 0u;
         uint32_t slot = s_base + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
-        float4 *op = reinterpret_cast<float4 *>(rays_out + slot);
-        op[0] = o0; op[1] = o1; op[2] = o2;
+        rays_out.org[slot] = o0; rays_out.dir[slot] = o1; rays_out.thr[slot] = o2;
     }
 }
 
@@ -512,7 +518,7 @@ __global__ void __launch_bounds__(256) k_scale_copy(const float4 *src, float4 *d
 
 }  // namespace
 
-void launch_raygen(hipStream_t s, const FrameDev &f, uint32_t n_paths, RayRec *rays, uint32_t *counters)
+void launch_raygen(hipStream_t s, const FrameDev &f, uint32_t n_paths, RayQueue rays, uint32_t *counters)
 {
     uint32_t blocks = (n_paths + 255u) / 256u;
     hipLaunchKernelGGL(k_raygen, dim3(blocks ? blocks : 1u), dim3(256), 0, s, f, n_paths, rays, counters);
@@ -529,8 +535,8 @@ static const ExtendSched &extend_sched()
     return sched;
 }
 
-void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, const RayRec *rays, const uint32_t *count,
-                   uint32_t *next, uint32_t capacity, uint32_t max_waves, HitRec *hits, uint64_t *trav_totals)
+void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, RayQueue rays, const uint32_t *count,
+                   uint32_t *next, uint32_t capacity, uint32_t max_waves, HitOut *hits, uint64_t *trav_totals)
 {
     const ExtendSched &sched = extend_sched();
     uint32_t blocks = std::min((capacity + kExtendBlock - 1u) / kExtendBlock, max_waves);
@@ -549,7 +555,7 @@ uint32_t extend_resident_waves(int device)
 }
 
 void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
-                  const RayRec *rays_in, const HitRec *hits, uint32_t *counters, uint32_t capacity, RayRec *rays_out,
+                  RayQueue rays_in, const HitOut *hits, uint32_t *counters, uint32_t capacity, RayQueue rays_out,
                   float4 *results)
 {
     uint32_t blocks = (capacity + kShadeBlock - 1u) / kShadeBlock;

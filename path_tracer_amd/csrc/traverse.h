@@ -142,8 +142,9 @@ struct Traversal {
         // lanes' worth of fp32 per issue slot), and the meta bytes of four children are decoded
         // with byte-parallel integer ops.
         typedef float pk2 __attribute__((ext_vector_type(2)));
-        const pk2 axx = {ax, ax}, ayy = {ay, ay}, azz = {az, az};
-        const pk2 bxx = {bx, bx}, byy = {by, by}, bzz = {bz, bz};
+        // pairs: (x near, y near), (x far, y far), (z near, z far) -- the first two use both halves
+        // of their coefficient registers, only z needs a broadcast pair
+        const pk2 axy = {ax, ay}, bxy = {bx, by}, azz = {az, az}, bzz = {bz, bz};
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             uint32_t meta4 = n.w[6 + half];
@@ -157,14 +158,14 @@ struct Traversal {
             uint32_t cnt4 = (meta4 >> 5) & 0x07070707u;                         // unary triangle count (1 for inner)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                pk2 qx = {byte_f(nx4, k), byte_f(fx4, k)};
-                pk2 qy = {byte_f(ny4, k), byte_f(fy4, k)};
+                pk2 qn = {byte_f(nx4, k), byte_f(ny4, k)};
+                pk2 qf = {byte_f(fx4, k), byte_f(fy4, k)};
                 pk2 qz = {byte_f(nz4, k), byte_f(fz4, k)};
-                pk2 tx = __builtin_elementwise_fma(qx, axx, bxx);
-                pk2 ty = __builtin_elementwise_fma(qy, ayy, byy);
+                pk2 tnn = __builtin_elementwise_fma(qn, axy, bxy);
+                pk2 tff = __builtin_elementwise_fma(qf, axy, bxy);
                 pk2 tz = __builtin_elementwise_fma(qz, azz, bzz);
-                float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, t_min));
-                float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, hit.t));
+                float tn = fmaxf(fmaxf(tnn.x, tnn.y), fmaxf(tz.x, t_min));
+                float tf = fminf(fminf(tff.x, tff.y), fminf(tz.y, hit.t));
                 uint32_t bits = ((cnt4 >> (8 * k)) & 0xFFu) << ((bit4 >> (8 * k)) & 0xFFu);
                 if (tn <= tf) hitmask |= bits;
             }
