@@ -48,12 +48,11 @@ struct ptx_context {
     // device scene
     Bvh8Node *d_nodes = nullptr; uint32_t n_nodes = 0;
     TriRec *d_tris = nullptr; ShadeRec *d_shade = nullptr; uint64_t n_tris = 0;
-    ptx_material *d_materials = nullptr;
     TexDesc *d_textures = nullptr;
     float *d_lut = nullptr;
     uint32_t bvh_depth = 0;
     bool scene_ready = false;
-    bool materials_dirty = true, textures_dirty = true;
+    bool textures_dirty = true;
 
     // images (renderer.rs:476-531)
     uint32_t width = 0, height = 0;
@@ -233,7 +232,7 @@ int ptx_destroy(ptx_context *c)
     drain_events(c);
     for (EventPair &p : c->event_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (TexDesc &t : c->textures) { void *p = (void *)t.texels; if (p) (void)hipFree(p); }
-    dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_materials); dfree(c->d_textures); dfree(c->d_lut);
+    dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_textures); dfree(c->d_lut);
     dfree(c->d_albedo); dfree(c->d_normal); dfree(c->d_depth); dfree(c->d_ids);
     free_paths(c);
     dfree(c->d_counters); dfree(c->d_totals);
@@ -274,7 +273,6 @@ int ptx_add_material(ptx_context *c, const ptx_material *m, uint32_t *index)
         return fail(c, PTX_ERR_CAPACITY, "ptx_add_material: material buffer overflow"); // scene/mod.rs:347-349
     *index = (uint32_t)c->materials.size();
     c->materials.push_back(*m);
-    c->materials_dirty = true;
     return PTX_OK;
 }
 
@@ -379,9 +377,11 @@ int ptx_set_instances(ptx_context *c, const ptx_instance *inst, uint32_t n)
         memset(&sr, 0, sizeof sr);
         memcpy(sr.v0, tr.v0, 12); memcpy(sr.v1, tr.v1, 12); memcpy(sr.v2, tr.v2, 12);
         sr.instance = tr.instance; sr.prim = tr.prim;
+        const ptx_material &m = c->materials[in.off.material_offset];
+        sr.texture = m.has_base_texture ? m.base_texture_indice : 0xFFFFFFFFu;
+        sr.roughness = m.roughness; sr.base_r = m.base_color[0]; sr.base_g = m.base_color[1]; sr.base_b = m.base_color[2];
         memcpy(sr.n0, a.normal, 12); memcpy(sr.n1, b.normal, 12); memcpy(sr.n2, d.normal, 12);   // object space, as the reference
         memcpy(sr.uv0, a.uv, 8); memcpy(sr.uv1, b.uv, 8); memcpy(sr.uv2, d.uv, 8);
-        sr.material = in.off.material_offset;
     }
 
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -397,14 +397,6 @@ int ptx_set_instances(ptx_context *c, const ptx_instance *inst, uint32_t n)
         HIP_TRY(c, hipMemcpy(c->d_tris, tris.data(), nt * sizeof(TriRec), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMalloc((void **)&c->d_shade, nt * sizeof(ShadeRec)));
         HIP_TRY(c, hipMemcpy(c->d_shade, shade.data(), nt * sizeof(ShadeRec), hipMemcpyHostToDevice));
-    }
-    if (c->materials_dirty) {
-        dfree(c->d_materials);
-        if (!c->materials.empty()) {
-            HIP_TRY(c, hipMalloc((void **)&c->d_materials, c->materials.size() * sizeof(ptx_material)));
-            HIP_TRY(c, hipMemcpy(c->d_materials, c->materials.data(), c->materials.size() * sizeof(ptx_material), hipMemcpyHostToDevice));
-        }
-        c->materials_dirty = false;
     }
     if (c->textures_dirty) {
         dfree(c->d_textures);
@@ -461,7 +453,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
 
     SceneDev sc;
     sc.nodes = c->d_nodes; sc.n_nodes = c->n_nodes; sc.tris = c->d_tris; sc.shade = c->d_shade;
-    sc.materials = c->d_materials; sc.textures = c->d_textures; sc.srgb_lut = c->d_lut;
+    sc.textures = c->d_textures; sc.n_textures = (uint32_t)c->textures.size(); sc.srgb_lut = c->d_lut;
     ImagesDev img; img.albedo = c->d_albedo; img.normal = c->d_normal; img.depth = c->d_depth; img.ids = c->d_ids;
     FrameDev f;
     f.cam = *cam;

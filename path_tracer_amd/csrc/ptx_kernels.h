@@ -33,17 +33,20 @@ struct alignas(8) HitOut {
 };
 static_assert(sizeof(HitOut) == 8, "HitOut must be 8 bytes");
 
-// Per-triangle shading inputs in leaf order: what rchit.glsl:160-190 gathers through Offsets ->
-// indices -> 3 x Vertex -> material_offset, pre-joined at ptx_set_instances time, plus the
-// world-space positions (for the barycentrics) and the ids.  One 128-byte record = one L2 line
-// per shaded hit.
+// Per-triangle shading inputs in leaf order: what rchit.glsl:160-198 gathers through Offsets ->
+// indices -> 3 x Vertex -> material_offset -> Material, pre-joined at ptx_set_instances time, plus
+// the world-space positions (for the barycentrics) and the ids.  One 128-byte record = one L2 line
+// and ONE dependent fetch per shaded hit (the chain ray -> triangle -> material -> texture table
+// -> texel was five round trips deep).
 struct alignas(128) ShadeRec {
-    float v0[3]; uint32_t instance;
-    float v1[3]; uint32_t prim;
-    float v2[3]; uint32_t material;
+    float v0[3]; uint32_t texture;      // bindless index of the base-colour texture, 0xFFFFFFFF: none (shared.glsl:31-32)
+    float v1[3]; float roughness;
+    float v2[3]; float base_r;
     float n0[3], n1[3], n2[3];
     float uv0[2], uv1[2], uv2[2];
-    uint32_t _pad[5];
+    float base_g, base_b;
+    uint32_t instance, prim;
+    uint32_t _pad;
 };
 static_assert(sizeof(ShadeRec) == 128, "ShadeRec must be 128 bytes");
 
@@ -51,13 +54,14 @@ struct TexDesc {
     const uint8_t *texels;   // RGBA8, row 0 first
     uint32_t width, height, srgb, _pad;
 };
+static_assert(sizeof(TexDesc) == 24, "TexDesc must be 24 bytes");
+constexpr uint32_t kLdsTextures = 64;   // descriptors of the first textures are staged in LDS by the shading stage
 
 struct SceneDev {
     const Bvh8Node *nodes; uint32_t n_nodes;
     const TriRec *tris;
     const ShadeRec *shade;
-    const ptx_material *materials;
-    const TexDesc *textures;
+    const TexDesc *textures; uint32_t n_textures;
     const float *srgb_lut;   // 256 floats
 };
 

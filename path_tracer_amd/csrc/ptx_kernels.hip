@@ -23,9 +23,9 @@ namespace {
 
 constexpr int kExtendBlock = 64;    // one wave per workgroup: resources free as soon as the wave retires
 #ifndef PTX_SHADE_BLOCK
-#define PTX_SHADE_BLOCK 1024
+#define PTX_SHADE_BLOCK 512
 #endif
-constexpr int kShadeBlock = PTX_SHADE_BLOCK;   // one queue-tail atomic per 1024 rays: a single word takes only ~88 M atomics/s
+constexpr int kShadeBlock = PTX_SHADE_BLOCK;   // one queue-tail atomic per block (a single word takes only ~88 M atomics/s); 512 threads x 74 VGPRs = 6 waves/SIMD
 
 __device__ __forceinline__ f3 mat4_mul(const float *m, float x, float y, float z, float w)
 {
@@ -343,30 +343,53 @@ __device__ __forceinline__ f3 sample_texture(const TexDesc &tx, const float *lut
     return mk3((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f);
 }
 
+#ifdef PTX_SHADE_WAVES
+__attribute__((amdgpu_waves_per_eu(PTX_SHADE_WAVES, PTX_SHADE_WAVES)))
+#endif
 __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, ImagesDev img, uint32_t depth,
                                                         RayQueue rays_in,
                                                         const HitOut *__restrict__ hits,
-                                                        uint32_t *__restrict__ counters,
+                                                        uint32_t *__restrict__ counters, uint32_t capacity,
                                                         RayQueue rays_out, float4 *__restrict__ results)
 {
     __shared__ float s_lut[256];
+    __shared__ TexDesc s_tex[kLdsTextures];
     __shared__ uint32_t s_wave_live[kShadeBlock / 64], s_wave_hits[kShadeBlock / 64];
     __shared__ uint32_t s_base;
+
+    // Every fetch that does not depend on another is issued before the first wait: the ray, its
+    // hit and the live count together, then the triangle's record, while the sRGB table and the
+    // texture descriptors go to LDS.
+    const uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x;
+    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
+    float2 hr = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
+    if (i < capacity) {
+        r0 = rays_in.org[i]; r1 = rays_in.dir[i]; r2 = rays_in.thr[i];
+        hr = *reinterpret_cast<const float2 *>(hits + i);
+    }
+    const uint32_t n_live = counters[depth];
     if (threadIdx.x < 256) s_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];
+    {
+        const uint32_t nw = (sc.n_textures < kLdsTextures ? sc.n_textures : kLdsTextures) * (uint32_t)(sizeof(TexDesc) / 4);
+        for (uint32_t w = threadIdx.x; w < nw; w += kShadeBlock)
+            reinterpret_cast<uint32_t *>(s_tex)[w] = reinterpret_cast<const uint32_t *>(sc.textures)[w];
+    }
+    const bool valid = i < capacity && i < n_live;
+    const uint32_t tri = valid ? __float_as_uint(hr.y) : 0xFFFFFFFFu;
+    float4 t0 = r0, t1 = r0, t2 = r0, s0 = r0, s1 = r0, s2 = r0, s3 = r0, s4 = r0;
+    if (tri != 0xFFFFFFFFu) {
+        const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri);
+        t0 = sp[0]; t1 = sp[1]; t2 = sp[2]; s0 = sp[3]; s1 = sp[4]; s2 = sp[5]; s3 = sp[6]; s4 = sp[7];
+    }
     __syncthreads();
 
-    uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x;
-    bool valid = i < counters[depth];
     bool alive = false, was_hit = false;
     float4 o0, o1, o2;
     if (valid) {
-        float4 r0 = rays_in.org[i], r1 = rays_in.dir[i], r2 = rays_in.thr[i];
-        float2 hr = *reinterpret_cast<const float2 *>(hits + i);
         f3 ro = mk3(r0.x, r0.y, r0.z), rd = mk3(r1.x, r1.y, r1.z);
         uint32_t path = __float_as_uint(r0.w), uv_state = __float_as_uint(r1.w);
         uint32_t sample = path / f.n_pixels, pix = path - sample * f.n_pixels;
         uint32_t acc = f.mean_base + sample;            // uniforms.accumulated_count of this path's frame
-        uint32_t tri = __float_as_uint(hr.y);
 
         f3 att, normal, new_o = ro, new_d = rd;
         float dist;
@@ -381,8 +404,6 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
         } else {
             was_hit = true;
             // rchit.glsl:160-183
-            const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri);
-            float4 t0 = sp[0], t1 = sp[1], t2 = sp[2], s0 = sp[3], s1 = sp[4], s2 = sp[5], s3 = sp[6];
             f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
             // barycentrics of the hit, recomputed from the triangle (tri_uv == tri_test's u, v)
             float hu, hv;
@@ -392,16 +413,15 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
             float tu = (s2.y * bx + s2.w * by) + s3.y * bz;
             float tv = (s2.z * bx + s3.x * by) + s3.z * bz;
             f3 world_pos = ro + rd * hr.x;                                   // :186
-            uint32_t mi = __float_as_uint(t2.w);
-            const float4 *mp = reinterpret_cast<const float4 *>(sc.materials + mi);
-            float4 m0 = mp[0], m1 = mp[1];                                   // :190
             f3 albedo;
-            if (__float_as_uint(m1.x)) {                                     // :193-198
-                albedo = sample_texture(sc.textures[__float_as_uint(m1.y)], s_lut, tu, tv);
+            const uint32_t tex = __float_as_uint(t0.w);                      // :190-198
+            if (tex != 0xFFFFFFFFu) {
+                if (tex < kLdsTextures) albedo = sample_texture(s_tex[tex], s_lut, tu, tv);
+                else albedo = sample_texture(sc.textures[tex], s_lut, tu, tv);
             } else {
-                albedo = mk3(m0.x, m0.y, m0.z);
+                albedo = mk3(t2.w, s3.w, s4.x);
             }
-            float roughness = m1.w;                                          // :200
+            float roughness = t1.w;                                          // :200
             float k2 = 2.0f * dot(normal, rd);                               // :209 reflect()
             f3 reflected = rd - normal * k2;
             f3 rr = normalize(cosine_hemisphere_sample(uv_state, depth, acc + f.rng_offset, f.seed, normal));
@@ -418,7 +438,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
             new_d = scatter;
             dist = length(new_o - ro);                                       // :254
             if (depth == 0 && sample == f.ids_sample) {
-                id_inst = __float_as_uint(t0.w); id_prim = __float_as_uint(t1.w);
+                id_inst = __float_as_uint(s4.y); id_prim = __float_as_uint(s4.z);
             }
         }
         f3 thr = mk3(r2.x, r2.y, r2.z) * att;                                // rgen.glsl:80
@@ -561,7 +581,7 @@ void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const Im
     uint32_t blocks = (capacity + kShadeBlock - 1u) / kShadeBlock;
     if (!blocks) return;
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kShadeBlock), 0, s, sc, f, img, depth, rays_in, hits, counters,
-                       rays_out, results);
+                       capacity, rays_out, results);
 }
 
 void launch_resolve(hipStream_t s, const FrameDev &f, const ImagesDev &img, const float4 *results, uint32_t n_samples)
