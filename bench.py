@@ -38,7 +38,8 @@ WORKLOADS = {
                         res=(512, 512), geometry="real"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 80, 48, 32, 16
+# per node visit, per triangle test (48 B of vertices + the 12 B ray direction it re-reads), ray fetch, hit record
+NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 80, 60, 32, 8
 
 
 def main():
