@@ -62,6 +62,9 @@ __global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, Ra
     rays.org[p] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(p));
     rays.dir[p] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(hash2(f2u(uvx), f2u(uvy))));
     rays.thr[p] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);   // rgen.glsl:62
+    float ix, iy, iz;
+    uint32_t oct = ray_slab_setup(origin, dir, ix, iy, iz);
+    rays.inv[p] = make_float4(ix, iy, iz, __uint_as_float(oct));
 }
 
 // ---------------------------------------------------------------- extend
@@ -170,7 +173,7 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
     st.sp = 0;
     Traversal<LaneStack, kStats> tr;
     tr.ng_mask = 0; tr.tg_mask = 0;
-    tr.o = mk3(0.0f, 0.0f, 0.0f); tr.d = mk3(0.0f, 0.0f, 1.0f); tr.hit.t = 0.0f;
+    tr.o = mk3(0.0f, 0.0f, 0.0f); tr.hit.t = 0.0f;
     tr.t_min = t_min; tr.t_max = t_max;     // wave-uniform: keeps them out of the VGPRs
     bool active = false;
     bool exhausted = false;
@@ -200,8 +203,8 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                 uint32_t avail = chunk_end - chunk_next;
                 if (!active && rank < avail) {
                     uint32_t i = chunk_next + rank;
-                    float4 r0 = rays.org[i], r1 = rays.dir[i];
-                    bool go = tr.init(sc.n_nodes, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), t_min, t_max, st);
+                    float4 r0 = rays.org[i], r3 = rays.inv[i];
+                    bool go = tr.init_prepared(sc.n_nodes, mk3(r0.x, r0.y, r0.z), r3.x, r3.y, r3.z, __float_as_uint(r3.w), t_min, t_max, st);
                     next_ni = go ? tr.node_pick(st) : 0xFFFFFFFFu;
                     ray = i;
                     my_tail = q_head;
@@ -384,7 +387,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
     __syncthreads();
 
     bool alive = false, was_hit = false;
-    float4 o0, o1, o2;
+    float4 o0, o1, o2, o3;
     if (valid) {
         f3 ro = mk3(r0.x, r0.y, r0.z), rd = mk3(r1.x, r1.y, r1.z);
         uint32_t path = __float_as_uint(r0.w), uv_state = __float_as_uint(r1.w);
@@ -461,6 +464,9 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
             o0 = make_float4(new_o.x, new_o.y, new_o.z, r0.w);
             o1 = make_float4(new_d.x, new_d.y, new_d.z, r1.w);
             o2 = make_float4(thr.x, thr.y, thr.z, 0.0f);
+            float ix, iy, iz;
+            uint32_t oct = ray_slab_setup(new_o, new_d, ix, iy, iz);
+            o3 = make_float4(ix, iy, iz, __uint_as_float(oct));
         }
     }
 
@@ -493,7 +499,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
     if (alive) {
         uint32_t before = wave ? s_wave_live[wave - 1] : 0u;
         uint32_t slot = s_base + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
-        rays_out.org[slot] = o0; rays_out.dir[slot] = o1; rays_out.thr[slot] = o2;
+        rays_out.org[slot] = o0; rays_out.dir[slot] = o1; rays_out.thr[slot] = o2; rays_out.inv[slot] = o3;
     }
 }
 

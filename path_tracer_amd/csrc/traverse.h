@@ -67,6 +67,22 @@ PT_HD float byte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); 
 
 struct TraverseStats { uint32_t nodes, tris; };
 
+// Per-ray constants of the slab tests: reciprocal direction (|d| clamped away from 0 so that no
+// 0 * inf NaN can arise) and the octant word -- bits 2..0 = octinv, kRayDegenerate if the ray is
+// non-finite and must miss everything.
+constexpr uint32_t kRayDegenerate = 0x80000000u;
+PT_HD uint32_t ray_slab_setup(f3 org, f3 dir, float &ix, float &iy, float &iz)
+{
+    const float tiny = 1e-18f;
+    float dx = fabsf(dir.x) > tiny ? dir.x : copysignf(tiny, dir.x);
+    float dy = fabsf(dir.y) > tiny ? dir.y : copysignf(tiny, dir.y);
+    float dz = fabsf(dir.z) > tiny ? dir.z : copysignf(tiny, dir.z);
+    ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
+    uint32_t oct = (dx < 0.0f ? 0u : 4u) | (dy < 0.0f ? 0u : 2u) | (dz < 0.0f ? 0u : 1u);
+    if (!finite3(org) || !finite3(dir)) oct |= kRayDegenerate;
+    return oct;
+}
+
 // Stack: any type with push(uint32_t, uint32_t), pop(uint32_t&, uint32_t&), empty(), clear().
 template <class Stack, bool kStats>
 struct Traversal {
@@ -86,21 +102,27 @@ struct Traversal {
     // rays hit nothing, the same rule as the oracle).
     PT_HD bool init(uint32_t n_nodes, f3 org, f3 dir, float tmin, float tmax, Stack &stack)
     {
-        o = org; d = dir; t_min = tmin; t_max = tmax;
+        d = dir;
+        float ix, iy, iz;
+        uint32_t oct = ray_slab_setup(org, dir, ix, iy, iz);
+        return init_prepared(n_nodes, org, ix, iy, iz, oct, tmin, tmax, stack);
+    }
+
+    // Same with the slab set-up already done (the GPU stages that CREATE a ray do it at full lane
+    // utilisation and pass it through the ray queue; `d` is not kept).
+    PT_HD bool init_prepared(uint32_t n_nodes, f3 org, float ix, float iy, float iz, uint32_t oct, float tmin, float tmax,
+                             Stack &stack)
+    {
+        o = org; t_min = tmin; t_max = tmax;
         hit.t = tmax; hit.u = 0.0f; hit.v = 0.0f; hit.tri = 0xFFFFFFFFu;
         best_inst = 0xFFFFFFFFu; best_prim = 0xFFFFFFFFu;
         stats.nodes = 0; stats.tris = 0;
         stack.clear();
         tg_base = 0; tg_mask = 0;
         ng_base = 0; ng_mask = 0;
-        if (n_nodes == 0 || !finite3(org) || !finite3(dir)) return false;
-        // |d| clamped away from 0 so that no 0 * inf NaN can arise in the slab tests
-        const float tiny = 1e-18f;
-        float dx = fabsf(dir.x) > tiny ? dir.x : copysignf(tiny, dir.x);
-        float dy = fabsf(dir.y) > tiny ? dir.y : copysignf(tiny, dir.y);
-        float dz = fabsf(dir.z) > tiny ? dir.z : copysignf(tiny, dir.z);
-        idx = 1.0f / dx; idy = 1.0f / dy; idz = 1.0f / dz;
-        octinv = (dx < 0.0f ? 0u : 4u) | (dy < 0.0f ? 0u : 2u) | (dz < 0.0f ? 0u : 1u);
+        idx = ix; idy = iy; idz = iz;
+        octinv = oct & 7u;
+        if (n_nodes == 0 || (oct & kRayDegenerate)) return false;
         ng_mask = 0x80000000u;   // the root as the single pending child of a virtual group (imask 0 -> index 0)
         return true;
     }
