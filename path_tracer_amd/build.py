@@ -13,7 +13,7 @@ LIB = os.path.join(HERE, "libptx_amd.so")
 SOURCES = ["ptx_api.cpp", "ptx_kernels.hip", "bvh_build.cpp", "ptx_rccl.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: shading / triangle-test arithmetic must round exactly like the CPU oracle's.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fPIC",
          "-Wall", "-Wno-unused-function", "-x", "hip"] + os.environ.get("PTX_EXTRA_FLAGS", "").split()
 
 
