@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <limits>
@@ -30,10 +31,13 @@ struct Box {
     }
 };
 
+float env_float(const char *name, float dflt);
+
 struct Node2 {
     Box box;
     uint32_t left = 0, right = 0;   // children (inner)
     uint32_t first = 0, count = 0;  // leaf range in `order` (count > 0 => leaf)
+    uint32_t tfirst = 0, tcount = 0; // triangle range of the whole subtree (contiguous in `order`)
 };
 
 struct Builder2 {
@@ -51,6 +55,7 @@ struct Builder2 {
     void build(uint32_t node, uint32_t first, uint32_t count, int spawn_depth)
     {
         Node2 &n = nodes[node];
+        n.tfirst = first; n.tcount = count;
         Box cb; cb.reset(); n.box.reset();
         for (uint32_t i = first; i < first + count; ++i) {
             uint32_t t = order[i];
@@ -125,6 +130,12 @@ struct Builder2 {
     }
 };
 
+float env_float(const char *name, float dflt)
+{
+    const char *e = getenv(name);
+    return e ? (float)atof(e) : dflt;
+}
+
 inline float step_of(uint8_t e) { uint32_t u = (uint32_t)e << 23; float f; memcpy(&f, &u, 4); return f; }
 
 }  // namespace
@@ -179,7 +190,59 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
     while ((1 << spawn) < std::max(1, n_threads)) ++spawn;
     b2.build(0, 0, n, spawn);
 
-    // ---- collapse to 8-wide, breadth-first so that a node's internal children are contiguous ----
+    // ---- collapse to 8-wide ----
+    // Which BVH2 nodes become the (up to 8) children of each wide node is chosen by the dynamic
+    // programme of Ylitie, Karras & Laine, "Efficient Incoherent Ray Traversal on GPUs Through
+    // Compressed Wide BVHs" (HPG 2017, section 3.1): C(n, i) = cheapest SAH cost of the subtree of
+    // n when it may occupy i child slots of its parent; a subtree of <= 3 triangles may become one
+    // leaf slot.  A greedy open-the-largest-child collapse left the nodes half empty (4.1 of 8
+    // slots on the Sponza stand-in), and every visit pays for all 8 slots.
+    const uint32_t n2 = b2.n_nodes.load();
+    const float c_node = env_float("PTX_BVH_CNODE", 1.8f), c_prim = env_float("PTX_BVH_CPRIM", 1.0f);
+    const float inf = std::numeric_limits<float>::infinity();
+    struct Dp { float c[8]; uint8_t k[9]; uint8_t leaf; };      // c[i], i = 1..7; k[j], j = 2..8: slots given to the left child
+    std::vector<Dp> dp(n2);
+    for (uint32_t ni = n2; ni-- > 0;) {                          // children have larger indices than their parent
+        const Node2 &nd2 = b2.nodes[ni];
+        if (ni != 0 && nd2.tcount == 0) continue;                // the unused second half of an allocation
+        Dp &d = dp[ni];
+        float area = nd2.box.half_area();
+        float c_leaf = nd2.tcount <= Builder2::kMaxLeaf ? area * (float)nd2.tcount * c_prim : inf;
+        if (nd2.count > 0) {
+            for (int i = 1; i <= 7; ++i) d.c[i] = c_leaf;
+            d.leaf = 1;
+            continue;
+        }
+        const Dp &L = dp[nd2.left], &R = dp[nd2.right];
+        float dist[9];
+        for (int j = 2; j <= 8; ++j) {
+            float best = inf; int bk = 1;
+            for (int k = 1; k < j; ++k) {
+                if (k > 7 || j - k > 7) continue;
+                float v = L.c[k] + R.c[j - k];
+                if (v < best) { best = v; bk = k; }
+            }
+            dist[j] = best; d.k[j] = (uint8_t)bk;
+        }
+        float c_internal = dist[8] + area * c_node;
+        d.leaf = c_leaf <= c_internal;
+        d.c[1] = d.leaf ? c_leaf : c_internal;
+        for (int i = 2; i <= 7; ++i) d.c[i] = std::min(dist[i], d.c[i - 1]);
+    }
+    // children of the wide node rooted at BVH2 node `n` when it may use `i` slots
+    struct Gather {
+        const std::vector<Node2> &nodes; const std::vector<Dp> &dp;
+        void run(uint32_t n, int i, uint32_t *kids, int &nk) const
+        {
+            const Dp &d = dp[n];
+            while (i > 1 && !(d.c[i] < d.c[i - 1])) --i;         // C(n, i) fell back to fewer slots
+            if (i == 1 || nodes[n].count > 0) { kids[nk++] = n; return; }
+            int k = d.k[i];
+            run(nodes[n].left, k, kids, nk);
+            run(nodes[n].right, i - k, kids, nk);
+        }
+    } gather{b2.nodes, dp};
+
     struct Pending { uint32_t node2; uint32_t depth; };
     std::vector<Pending> queue;
     queue.push_back({0u, 1u});
@@ -191,22 +254,12 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
         out.depth = std::max(out.depth, depth);
 
         uint32_t kids[8]; int nk = 0;
-        if (src.count > 0) {
+        if (src.count > 0 || dp[queue[qi].node2].leaf) {
             kids[nk++] = queue[qi].node2;             // a leaf root becomes the single leaf slot
         } else {
-            kids[nk++] = src.left; kids[nk++] = src.right;
-            for (;;) {                                // open the inner child of largest area
-                if (nk == 8) break;
-                int pick = -1; float best = -1.0f;
-                for (int i = 0; i < nk; ++i) {
-                    const Node2 &c = b2.nodes[kids[i]];
-                    if (c.count == 0 && c.box.half_area() > best) { best = c.box.half_area(); pick = i; }
-                }
-                if (pick < 0) break;
-                uint32_t open = kids[pick];
-                kids[pick] = b2.nodes[open].left;
-                kids[nk++] = b2.nodes[open].right;
-            }
+            int k = dp[queue[qi].node2].k[8];
+            gather.run(src.left, k, kids, nk);
+            gather.run(src.right, 8 - k, kids, nk);
         }
 
         // slot assignment: slot s is visited first by rays whose direction is negative exactly
@@ -262,20 +315,20 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
                 while (hi < 255 && nd.p[a] + (float)hi * st < ch.box.hi[a]) ++hi;
                 nd.qlo[a][s] = (uint8_t)lo; nd.qhi[a][s] = (uint8_t)hi;
             }
-            if (ch.count == 0) {
+            if (!dp[kids[c]].leaf) {
                 nd.imask |= (uint8_t)(1u << s);
                 nd.meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
                 ++n_inner;
             } else {
-                nd.meta[s] = (uint8_t)((((1u << ch.count) - 1u) << 5) | tri_off);
-                for (uint32_t i = 0; i < ch.count; ++i) out.tri_order.push_back(b2.order[ch.first + i]);
-                tri_off += ch.count;
+                nd.meta[s] = (uint8_t)((((1u << ch.tcount) - 1u) << 5) | tri_off);
+                for (uint32_t i = 0; i < ch.tcount; ++i) out.tri_order.push_back(b2.order[ch.tfirst + i]);
+                tri_off += ch.tcount;
             }
         }
         // internal children in slot order => relative index = popcount(imask below the slot)
         for (int s = 0; s < 8; ++s) {
             int c = slot_child[s];
-            if (c < 0 || b2.nodes[kids[c]].count != 0) continue;
+            if (c < 0 || dp[kids[c]].leaf) continue;
             queue.push_back({kids[c], depth + 1});
         }
         out.nodes.resize(out.nodes.size() + n_inner);
