@@ -27,6 +27,53 @@ def lion_boulder():
     return ingest(("lion_head_2k/lion_head_2k.gltf", (2, 0, 0)), ("boulder_01_2k/boulder_01_2k.gltf", (-2, 0, 0)))
 
 
+def stress_scene(n_textures=70, n_confetti=12000, n_layers=24, seed=7):
+    """Synthetic scene for the paths ordinary assets do not reach: more textures than the shading
+    stage keeps in LDS (64), sRGB and linear textures, uv far outside [0, 1] (clamp), stacks of
+    exactly coincident quads (equal-t ties -> lowest (instance, primitive)), and leaf-heavy nodes
+    that overflow the traversal's per-wave triangle queue."""
+    from oracle.gltf_ingest import IngestedScene, MATERIAL_DTYPE, VERTEX_DTYPE
+    rng = np.random.default_rng(seed)
+    ing = IngestedScene()
+    for t in range(n_textures):
+        ing.textures.append((rng.integers(0, 256, size=(4 + t % 3, 3 + t % 5, 4), dtype=np.uint8), t % 2))
+    mats = []
+    for t in range(n_textures):
+        m = np.zeros(1, dtype=MATERIAL_DTYPE)
+        m["base_color"] = rng.random(4, dtype=np.float32)
+        m["has_base_texture"] = 1 if t % 4 != 3 else 0
+        m["base_texture_indice"] = t
+        m["metallic"] = 0.0
+        m["roughness"] = np.float32([1.0, 0.0, 0.5, 0.25][t % 4])
+        mats.append(ing.add_material(m))
+
+    def add_entity(name, pos3, idx, mat, xf=((0, 0, 0), (0, 0, 0, 1), (1, 1, 1))):
+        v = np.zeros(len(pos3), dtype=VERTEX_DTYPE)
+        v["position"] = pos3
+        from oracle.gltf_ingest import calculate_normals
+        v["normal"] = calculate_normals(np.asarray(pos3, np.float32), np.asarray(idx, np.uint32))
+        v["uv"] = rng.uniform(-1.5, 2.5, size=(len(pos3), 2)).astype(np.float32)
+        geom = ing._geometry_create(name, v, np.asarray(idx, np.uint32))
+        ing.entities.append((geom, (np.float32(xf[0]), np.float32(xf[1]), np.float32(xf[2])), mat))
+
+    # confetti: small random triangles in a 4 m cube, one entity per material
+    per = n_confetti // n_textures
+    for t in range(n_textures):
+        c = rng.uniform(-2, 2, size=(per, 1, 3)).astype(np.float32)
+        tri = (c + rng.normal(0, 0.08, size=(per, 3, 3)).astype(np.float32)).reshape(-1, 3)
+        add_entity("confetti%d" % t, tri, np.arange(per * 3), mats[t])
+    # coincident layers: the same quad n_layers times, as separate instances AND duplicated inside one geometry
+    quad = np.float32([[-1.5, -1.5, -2.5], [1.5, -1.5, -2.5], [1.5, 1.5, -2.5], [-1.5, 1.5, -2.5]])
+    dup_idx = np.tile(np.uint32([0, 1, 2, 0, 2, 3]), n_layers)
+    add_entity("stack", quad, dup_idx, mats[1])
+    for l in range(n_layers):
+        add_entity("layer", quad, np.uint32([0, 1, 2, 0, 2, 3]), mats[(5 + l) % n_textures])   # same ident: one geometry, many instances
+    # a floor so that paths bounce
+    floor = np.float32([[-6, -2.2, -6], [6, -2.2, -6], [6, -2.2, 6], [-6, -2.2, 6]])
+    add_entity("floor", floor, np.uint32([0, 2, 1, 0, 3, 2]), mats[3])
+    return ing
+
+
 def upload(ctx, ing, oracle):
     """Drives the C ABI the way the reference's loaders drive Scene/Renderer."""
     from path_tracer_amd import capi

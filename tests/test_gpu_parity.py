@@ -5,7 +5,7 @@ normal and depth images as well."""
 import numpy as np
 import pytest
 
-from helpers import SEED, assert_images_bit_equal, cornell, gpu_render, lion_boulder, rel_mse, upload
+from helpers import SEED, assert_images_bit_equal, cornell, gpu_render, lion_boulder, rel_mse, stress_scene, upload
 
 pytestmark = pytest.mark.gpu
 
@@ -63,3 +63,19 @@ def test_lion_boulder_textured_bit_exact(oracle, gpu_ctx_factory):
     assert_images_bit_equal(got, want, "lion+boulder 320x180x4")
     assert want["stats"]["textured_hits"] > 0
     assert rel_mse(got["albedo"], want["albedo"]) == 0.0
+
+
+def test_stress_scene_ties_queue_overflow_many_textures(oracle, gpu_ctx_factory):
+    """Coincident stacks (equal-t ties), leaf-heavy nodes (the per-wave triangle queue overflows and the
+    lanes retry), 70 textures (descriptors beyond the 64 staged in LDS), linear + sRGB texels, clamped uv."""
+    ing = stress_scene()
+    ctx = gpu_ctx_factory()
+    upload(ctx, ing, oracle)
+    sc = oracle.scene_from_ingest(ing)
+    from path_tracer_amd import capi
+    for pos, yaw in (([0.0, 0.2, 4.5], 0.0), ([0.3, -0.4, -1.0], 180.0)):
+        cam = oracle.camera_matrices(pos, oracle.yaw_quat(yaw), np.deg2rad(np.float32(60)), 1.0, 0.1, 1000.0)
+        want = sc.render(cam, 160, 160, 3, SEED, params=oracle.default_params(max_depth=6))
+        got = gpu_render(ctx, oracle, cam, 160, 160, 3, params=capi.default_params(max_depth=6))
+        assert_images_bit_equal(got, want, "stress scene from %s" % (pos,))
+    assert want["stats"]["textured_hits"] > 0
