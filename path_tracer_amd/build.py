@@ -39,6 +39,23 @@ def build_host(force=False, verbose=False):
     return HOST_LIB
 
 
+CLI = os.path.join(HERE, "ptx-render")
+
+
+def build_cli(force=False, verbose=False):
+    """The headless driver (host/ptx_render_main.cpp) over libpt_host.so + libptx_amd.so."""
+    src = os.path.join(HOST_DIR, "ptx_render_main.cpp")
+    if (not force and os.path.exists(CLI) and os.path.exists(HOST_LIB)
+            and os.path.getmtime(CLI) >= max(os.path.getmtime(src), os.path.getmtime(HOST_LIB))):
+        return CLI
+    cmd = [CXX, "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", CLI, src, "-L" + HERE, "-lpt_host", "-lptx_amd",
+           "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return CLI
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -73,4 +90,5 @@ def build_library(force=False, verbose=False):
 if __name__ == "__main__":
     build_library(force="--force" in sys.argv, verbose=True)
     build_host(force="--force" in sys.argv, verbose=True)
-    print(LIB, HOST_LIB)
+    build_cli(force="--force" in sys.argv, verbose=True)
+    print(LIB, HOST_LIB, CLI)

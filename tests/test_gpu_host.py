@@ -81,3 +81,49 @@ def test_renderer_frames_match_oracle_and_dirty_rules(oracle, tmp_path):
     with pytest.raises(host.HostError, match="File already exists"):
         r.save_render_texture_to_file(out)
     r.close()
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        kind = f.readline().strip()
+        w, h = map(int, f.readline().split())
+        scale = float(f.readline())
+        assert scale < 0                                          # little endian
+        ch = 3 if kind == b"PF" else 1
+        a = np.frombuffer(f.read(), dtype="<f4").reshape(h, w, ch)
+    return a[::-1]                                                # PFM stores the bottom row first
+
+
+def test_headless_cli_matches_the_host_renderer(tmp_path):
+    """ptx-render writes the same accumulation / normal / depth images (PFM) and the same PNG as the
+    in-process host mirror driven with the same arguments."""
+    import subprocess
+    from path_tracer_amd import build, capi, host
+    cli = build.build_cli()
+    gltf = os.path.join(ASSETS, "cornell/cornell.gltf")
+    out = str(tmp_path / "cli")
+    r = subprocess.run([cli, gltf, "--res", "96x64", "--spp", "5", "--seed", "19088743", "--depth", "8",
+                        "--camera", "0,1.0,3.9", "--yaw", "0", "--fov", "40", "--out", out],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    import json
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["samples"] == 96 * 64 * 6 and rep["rays"] > rep["samples"]      # 1 settle frame + 5 accumulated
+
+    R = host.Renderer(96, 64)
+    R.import_gltf(gltf)
+    R.set_camera([0, 1.0, 3.9], host.yaw_quat(0.0), np.deg2rad(np.float32(40.0)), 0.1, 1000.0)
+    R.set_seed(19088743, True)
+    R.set_params(capi.default_params(max_depth=8))
+    R.record_commands()
+    R.record_commands_batch(5)
+    alb, nrm, dep = R.read_image(capi.IMAGE_ALBEDO), R.read_image(capi.IMAGE_NORMAL), R.read_image(capi.IMAGE_DEPTH)
+    assert np.array_equal(read_pfm(out + "_albedo.pfm").view(np.uint32), alb[..., :3].view(np.uint32))
+    assert np.array_equal(read_pfm(out + "_normal.pfm").view(np.uint32), nrm[..., :3].view(np.uint32))
+    assert np.array_equal(read_pfm(out + "_depth.pfm")[..., 0].view(np.uint32), dep.reshape(64, 96).view(np.uint32))
+    R.save_render_texture_to_file(str(tmp_path / "host.png"))
+    assert open(out + ".png", "rb").read() == open(tmp_path / "host.png", "rb").read()
+    R.close()
+    # an existing output is not overwritten (renderer.rs:752-754)
+    r = subprocess.run([cli, gltf, "--res", "8x8", "--spp", "1", "--out", out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "exists" in r.stderr.lower()

@@ -191,3 +191,24 @@ def test_standins_are_deterministic_and_match_the_declared_layout(tmp_path):
         assert np.all(pos >= np.array(acc["min"], np.float32) - 1e-3) and np.all(pos <= np.array(acc["max"], np.float32) + 1e-3)
         idx = _accessor(doc, buf, p["indices"])
         assert idx.max() < acc["count"]
+
+
+def test_headless_cli_builds_and_validates_arguments(tmp_path):
+    """ptx-render: the binary links against the two libraries and rejects bad command lines
+    before touching a GPU; without a HIP device a render attempt fails loudly (no CPU fallback)."""
+    from path_tracer_amd import build
+    cli = build.build_cli()
+    assert os.path.exists(cli)
+    r = subprocess.run([cli, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "usage: ptx-render" in r.stderr
+    r = subprocess.run([cli], capture_output=True, text=True)
+    assert r.returncode == 2
+    r = subprocess.run([cli, "x.gltf", "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 2 and "unknown option" in r.stderr
+    r = subprocess.run([cli, "x.gltf", "--spp", "2", "--gpus", "3"], capture_output=True, text=True)
+    assert r.returncode == 2                                     # more GPUs than samples
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([cli, os.path.join(ASSETS, "cornell/cornell.gltf"), "--res", "8x8", "--spp", "1",
+                            "--out", str(tmp_path / "o")], capture_output=True, text=True)
+        assert r.returncode == 1 and "ptx-render:" in r.stderr and not (tmp_path / "o.png").exists()
