@@ -364,6 +364,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
     // hit and the live count together, then the triangle's record, while the sRGB table and the
     // texture descriptors go to LDS.
     const uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x;
+    if (blockIdx.x * kShadeBlock >= counters[depth]) return;      // the grid covers the chunk's capacity, the queue may be far shorter
     float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
     float2 hr = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
     if (i < capacity) {
