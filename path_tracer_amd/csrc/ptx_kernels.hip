@@ -176,7 +176,6 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
     tr.o = mk3(0.0f, 0.0f, 0.0f); tr.hit.t = 0.0f;
     tr.t_min = t_min; tr.t_max = t_max;     // wave-uniform: keeps them out of the VGPRs
     bool active = false;
-    bool exhausted = false;
     uint32_t ray = 0;
     uint32_t next_ni = 0xFFFFFFFFu;
     uint32_t q_head = 0, q_tail = 0;    // wave-uniform, monotone (mod 2^32)
@@ -185,6 +184,10 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
     unsigned long long w_iters = 0, w_node_blocks = 0, w_node_lanes = 0, w_tri_blocks = 0, w_tri_lanes = 0, w_refills = 0;
     uint32_t chunk_next = 0, chunk_end = 0;
     const uint32_t chunk = sched.chunk;
+    // wave-uniform: the queue has been handed out completely.  At most ceil(n / chunk) waves can ever
+    // receive rays: on a short queue (late bounces, small frames) the rest of the grid starts out
+    // "exhausted" and leaves without paying a same-address atomic (~88 M/s chip-wide).
+    bool exhausted = (uint64_t)blockIdx.x * chunk >= n;
 
     for (;;) {
         unsigned long long idle = __ballot(!active);
