@@ -87,8 +87,37 @@ typedef struct {
     float normal_eps;             /* 0.001 */
     uint32_t rng_sample_offset;   /* added to accumulated_count for the RNG only (spp partition across GPUs); 0 */
     uint32_t flags;               /* reserved, 0 */
-    uint32_t _pad[2];
+    uint32_t integrator;          /* PTX_INTEGRATOR_REFERENCE (0, default): the reference's rchit/rmiss shading */
+    uint32_t _pad;
 } ptx_render_params;
+
+/* Build extensions past the reference (todo.md:4 "Proper lighting", todo.md:6
+ * "GLTF textures stretched").  None of them changes the default, reference-exact behaviour. */
+typedef enum {
+    PTX_INTEGRATOR_REFERENCE = 0, /* rchit.glsl:158-254 + rmiss.glsl:18-34, quirks included */
+    PTX_INTEGRATOR_LIT = 1        /* emissive triangles, next-event estimation with occlusion rays, glTF
+                                     metallic-roughness (Lambert + GGX) and smooth-dielectric BSDFs, Russian
+                                     roulette; specified by oracle/pt_oracle.c raygen_pixel_lit */
+} ptx_integrator;
+
+/* What a glTF material carries beyond material.rs:70-76; one row per material index. 32 B. */
+typedef struct {
+    float emissive[3];            /* emissiveFactor x KHR_materials_emissive_strength, linear radiance; 0 */
+    float transmission;           /* KHR_materials_transmission, 0..1; 0 */
+    float ior;                    /* KHR_materials_ior; 1.5 */
+    uint32_t _pad[3];
+} ptx_material_ext;
+
+typedef enum {
+    PTX_SCENE_WORLD_NORMALS = 1,        /* vertex normals go to world space by the inverse transpose of the instance
+                                           transform (rchit.glsl:175-179 leaves them in object space) */
+    PTX_SCENE_TEXTURE_TIMES_FACTOR = 2  /* albedo = texel x baseColorFactor (rchit.glsl:193-195 drops the factor) */
+} ptx_scene_option;
+
+/* ptx_add_texture `srgb` argument as a flag word: bit0 sRGB decode, bit1 wrap = repeat instead of the
+ * reference's clamp-to-edge (graphics.rs:446-459 reads the glTF sampler and then ignores it). */
+#define PTX_TEXTURE_SRGB 1
+#define PTX_TEXTURE_REPEAT 2
 
 /* Fixed buffer capacities; defaults are the reference's (scene/mod.rs:48-54, renderer.rs:180). */
 typedef struct {
@@ -119,6 +148,8 @@ typedef struct {
     uint32_t bvh_depth, _pad;
     uint64_t nodes_fetched, tris_tested;   /* BVH nodes fetched / triangles tested; counted only at profiling level 2 */
     uint64_t wave_sched[6];                /* level 2: wave iterations, node blocks, lanes in them, triangle blocks, lanes in them, refills */
+    uint64_t shadow_rays;                  /* lit integrator: occlusion queries (not counted in rays) */
+    uint64_t lights;                       /* emissive triangles in the light table */
 } ptx_stats;
 
 typedef struct ptx_context ptx_context;
@@ -135,6 +166,12 @@ void ptx_default_params(ptx_render_params *params);
 int ptx_add_vertices(ptx_context *ctx, const ptx_vertex *vertices, uint64_t n, uint64_t *first);
 int ptx_add_indices(ptx_context *ctx, const uint32_t *indices, uint64_t n, uint64_t *first);
 int ptx_add_material(ptx_context *ctx, const ptx_material *material, uint32_t *index);
+
+/* Build extension: extended properties of material `index` (see ptx_material_ext).  Takes effect at the next
+ * ptx_set_instances.  No counterpart in the reference. */
+int ptx_set_material_ext(ptx_context *ctx, uint32_t index, const ptx_material_ext *ext);
+/* Build extension: bitwise OR of ptx_scene_option; takes effect at the next ptx_set_instances. */
+int ptx_set_scene_options(ptx_context *ctx, uint32_t options);
 
 /* Renderer::add_texture after Texture::from_gltf (renderer.rs:878, graphics.rs:383):
  * decoded 8-bit RGBA texels, row 0 first; srgb=1 is R8G8B8A8_SRGB.  Sampled as the

@@ -24,6 +24,9 @@ MATERIAL_DTYPE = np.dtype([("base_color", "<f4", 4), ("has_base_texture", "<u4")
 OFFSETS_DTYPE = np.dtype([("vertex_offset", "<u4"), ("vertex_count", "<u4"), ("material_offset", "<u4"),
                           ("padding", "<u4"), ("index_offset", "<u4"), ("index_count", "<u4")])
 INSTANCE_DTYPE = np.dtype([("xform", "<f4", (3, 4)), ("geometry", "<u4"), ("off", OFFSETS_DTYPE)])
+# build extension: what glTF materials carry beyond material.rs:70-76
+MATERIAL_EXT_DTYPE = np.dtype([("emissive", "<f4", 3), ("transmission", "<f4"), ("ior", "<f4"), ("_pad", "<u4", 3)])
+assert MATERIAL_EXT_DTYPE.itemsize == 32
 assert VERTEX_DTYPE.itemsize == 48 and MATERIAL_DTYPE.itemsize == 32
 assert OFFSETS_DTYPE.itemsize == 24 and INSTANCE_DTYPE.itemsize == 76
 
@@ -102,15 +105,42 @@ def _decompose(node):
     return t, q, s
 
 
+def _quat_mul(a, b):
+    ax, ay, az, aw = (np.float32(v) for v in a)
+    bx, by, bz, bw = (np.float32(v) for v in b)
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz], dtype=np.float32)
+
+
+def _quat_rotate(q, v):
+    b = np.asarray(q[:3], np.float32)
+    w = np.float32(q[3])
+    v = np.asarray(v, np.float32)
+    return (v * (w * w - np.dot(b, b)) + b * (np.dot(v, b) * np.float32(2)) + np.cross(b, v) * (w * np.float32(2))).astype(np.float32)
+
+
+def _compose(parent, child):
+    """parent * child for TRS triples.  Exact when the parent's scale is uniform (every shipped asset);
+    a non-uniformly scaled rotated parent has no TRS form and keeps the per-axis product."""
+    pt, pq, ps = parent
+    ct, cq, cs = child
+    return (pt + _quat_rotate(pq, ps * ct)).astype(np.float32), _quat_mul(pq, cq), (ps * cs).astype(np.float32)
+
+
 class IngestedScene:
     """What the reference's Scene + Renderer hold after import_gltf calls:
     shared vertex / index / material buffers, the bindless texture table and the
     entity list (geometry, transform, material) in push order."""
 
-    def __init__(self):
+    def __init__(self, ref_quirks=True):
+        # ref_quirks=False (SURVEY 8f.2, the --no-ref-quirks ingest): child nodes are imported with their
+        # accumulated transforms (gltf.rs:32-34 stops at the roots) and the glTF sampler's wrap mode is
+        # honoured (graphics.rs:446-451 reads it and drops it)
+        self.ref_quirks = ref_quirks
         self.vertices = np.zeros(0, dtype=VERTEX_DTYPE)
         self.indices = np.zeros(0, dtype=np.uint32)
         self.materials = np.zeros(0, dtype=MATERIAL_DTYPE)
+        self.material_ext = np.zeros(0, dtype=MATERIAL_EXT_DTYPE)
         self.textures = []          # list of (rgba8 HxWx4 uint8, srgb flag)
         self.texture_lookup = {}    # ident -> bindless index   (renderer.rs:867-873)
         self.geometries = {}        # ident -> (id, v_first, v_count, i_first, i_count)
@@ -127,8 +157,12 @@ class IngestedScene:
         self.indices = np.concatenate([self.indices, i.astype(np.uint32)])
         return first
 
-    def add_material(self, m):
+    def add_material(self, m, ext=None):
         self.materials = np.concatenate([self.materials, m])
+        if ext is None:
+            ext = np.zeros(1, dtype=MATERIAL_EXT_DTYPE)
+            ext["ior"] = 1.5
+        self.material_ext = np.concatenate([self.material_ext, ext])
         return len(self.materials) - 1
 
     def import_gltf(self, path, position_offset=(0.0, 0.0, 0.0), decode_image=None):
@@ -142,13 +176,20 @@ class IngestedScene:
                 buffers.append(f.read())
         offset = np.array(position_offset, dtype=np.float32)
         for scene in doc.get("scenes", []):
-            for ni in scene.get("nodes", []):
+            work = [(ni, None) for ni in scene.get("nodes", [])]
+            while work:
+                ni, parent = work.pop(0)
                 node = doc["nodes"][ni]
+                t, q, s = _decompose(node)
+                if not self.ref_quirks:
+                    # children in depth-first order after their parent; TRS composed parent * child
+                    if parent is not None:
+                        t, q, s = _compose(parent, (t, q, s))
+                    work = [(c, (t, q, s)) for c in node.get("children", [])] + work
                 if "mesh" not in node:
                     continue
                 mesh_index = node["mesh"]
                 mesh = doc["meshes"][mesh_index]
-                t, q, s = _decompose(node)
                 transform = (t + offset, q, s)                                   # gltf.rs:37-41
                 for prim_index, prim in enumerate(mesh["primitives"]):
                     mat_index = self._material_from_gltf(doc, prim.get("material"), base, decode_image)
@@ -188,26 +229,41 @@ class IngestedScene:
     def _material_from_gltf(self, doc, mat_idx, base, decode_image):
         """material.rs:34-90.  Every primitive appends a new Material row (no dedup)."""
         m = np.zeros(1, dtype=MATERIAL_DTYPE)
+        ext = np.zeros(1, dtype=MATERIAL_EXT_DTYPE)
+        ext["ior"] = 1.5
         pbr = {}
         if mat_idx is not None:
-            pbr = doc["materials"][mat_idx].get("pbrMetallicRoughness", {})
+            gm = doc["materials"][mat_idx]
+            pbr = gm.get("pbrMetallicRoughness", {})
+            x = gm.get("extensions", {})
+            strength = np.float32(x.get("KHR_materials_emissive_strength", {}).get("emissiveStrength", 1.0))
+            ext["emissive"] = np.array(gm.get("emissiveFactor", [0, 0, 0]), dtype=np.float32) * strength
+            ext["transmission"] = np.float32(x.get("KHR_materials_transmission", {}).get("transmissionFactor", 0.0))
+            ext["ior"] = np.float32(x.get("KHR_materials_ior", {}).get("ior", 1.5))
         m["base_color"] = np.array(pbr.get("baseColorFactor", [1, 1, 1, 1]), dtype=np.float32)
         m["metallic"] = np.float32(pbr.get("metallicFactor", 1.0))
         m["roughness"] = np.float32(pbr.get("roughnessFactor", 1.0))
         tex = pbr.get("baseColorTexture")
         if tex is not None:
-            image = doc["images"][doc["textures"][tex["index"]]["source"]]
+            gtex = doc["textures"][tex["index"]]
+            image = doc["images"][gtex["source"]]
             ident = "gltf_%s" % image["uri"]                                     # material.rs:59-61
+            flags = 1                                                            # R8G8B8A8_SRGB
+            if not self.ref_quirks:
+                samp = doc.get("samplers", [{}])[gtex["sampler"]] if "sampler" in gtex else {}
+                if samp.get("wrapS", 10497) == 10497 and samp.get("wrapT", 10497) == 10497:
+                    flags |= 2                                                   # wrap = repeat (glTF default)
+                    ident += "#repeat"
             if ident not in self.texture_lookup:                                 # graphics.rs:396-398
                 rgba = np.asarray((decode_image or decode_image_pil)(os.path.join(base, image["uri"])), np.uint8)
                 if rgba.shape[2] == 3:                                            # graphics.rs:507-516
                     rgba = np.concatenate([rgba, np.full(rgba.shape[:2] + (1,), 255, np.uint8)], axis=2)
                 rgba = np.ascontiguousarray(rgba)
-                self.textures.append((rgba, 1))                                  # R8G8B8A8_SRGB
+                self.textures.append((rgba, flags))
                 self.texture_lookup[ident] = len(self.textures) - 1
             m["has_base_texture"] = 1
             m["base_texture_indice"] = self.texture_lookup[ident]
-        return self.add_material(m)
+        return self.add_material(m, ext)
 
     def instances(self, xform_fn):
         """renderer.rs:912-955: one Offsets row + TLAS instance per entity, in push order.

@@ -188,11 +188,17 @@ float orc_srgb_to_linear(uint32_t c)
 typedef struct { v3 a, b, c; uint32_t instance, prim; } wtri;
 typedef struct { float lo[3], hi[3]; uint32_t left_first, count; } bnode;   /* count==0: inner, children left_first, left_first+1 */
 
+/* lit integrator: one emissive triangle of the light table */
+typedef struct { v3 a, b, c, n, le; float cdf, pdf_area; } light_t;
+
 struct orc_scene {
     orc_scene_desc d;
     wtri *tris;  uint64_t n_tris;
     uint32_t *order;             /* BVH leaf order -> tri index */
     bnode *nodes; uint32_t n_nodes;
+    uint64_t *inst_first;        /* first flattened triangle of each instance */
+    float (*cof)[9];             /* per instance: cofactor matrix of the 3x3 transform, sign of det folded in */
+    light_t *lights; uint64_t n_lights;
 };
 
 void orc_default_params(orc_params *p)
@@ -400,6 +406,95 @@ static void build_rec(bctx *c, uint32_t node, uint32_t first, uint32_t count)
     build_rec(c, l + 1, first + nl, count - nl);
 }
 
+/* Build extension (ORC_SCENE_WORLD_NORMALS): n_world ~ cofactor(M3) * n, with the sign of det(M3)
+ * folded in (= det * inverse transpose).  Rows of the cofactor matrix are cross products of M3's rows. */
+static void normal_matrix(const float m[3][4], float c[9])
+{
+    v3 r0 = v3_make(m[0][0], m[0][1], m[0][2]), r1 = v3_make(m[1][0], m[1][1], m[1][2]), r2 = v3_make(m[2][0], m[2][1], m[2][2]);
+    v3 c0 = v3_cross(r1, r2), c1 = v3_cross(r2, r0), c2 = v3_cross(r0, r1);
+    float det = v3_dot(r0, c0);
+    float sg = det < 0.0f ? -1.0f : 1.0f;
+    c[0] = c0.x * sg; c[1] = c0.y * sg; c[2] = c0.z * sg;
+    c[3] = c1.x * sg; c[4] = c1.y * sg; c[5] = c1.z * sg;
+    c[6] = c2.x * sg; c[7] = c2.y * sg; c[8] = c2.z * sg;
+}
+
+static inline v3 normal_to_world(const float c[9], v3 n)
+{
+    return v3_make((c[0] * n.x + c[1] * n.y) + c[2] * n.z, (c[3] * n.x + c[4] * n.y) + c[5] * n.z,
+                   (c[6] * n.x + c[7] * n.y) + c[8] * n.z);
+}
+
+static const orc_material_ext g_no_ext = { { 0.0f, 0.0f, 0.0f }, 0.0f, 1.5f, { 0, 0, 0 } };
+static inline const orc_material_ext *material_ext(const orc_scene *s, uint32_t m)
+{
+    return s->d.material_ext ? &s->d.material_ext[m] : &g_no_ext;
+}
+
+/* Lit integrator: the light table = every triangle whose material emits, in (instance, primitive)
+ * order; picked with probability proportional to area x luminance. */
+static int light_candidate(const orc_scene *s, const orc_material_ext *e, uint64_t k, v3 *cr, float *len, float *area, float *power)
+{
+    if (!(e->emissive[0] > 0.0f || e->emissive[1] > 0.0f || e->emissive[2] > 0.0f)) return 0;
+    const wtri *t = &s->tris[k];
+    *cr = v3_cross(v3_sub(t->b, t->a), v3_sub(t->c, t->a));
+    *len = sqrtf(v3_dot(*cr, *cr));
+    *area = 0.5f * *len;
+    if (!(*area > 0.0f) || !isfinite(*area)) return 0;
+    float lum = (0.2126f * e->emissive[0] + 0.7152f * e->emissive[1]) + 0.0722f * e->emissive[2];
+    *power = *area * lum;
+    return 1;
+}
+
+static void build_lights(orc_scene *s)
+{
+    s->lights = NULL; s->n_lights = 0;
+    if (!s->d.material_ext) return;
+    /* first pass: count and total power (double); second pass: fill */
+    uint64_t n = 0, k = 0;
+    double total = 0.0;
+    v3 cr; float len, area, power;
+    for (uint64_t i = 0; i < s->d.n_instances; ++i) {
+        const orc_instance *in = &s->d.instances[i];
+        const orc_material_ext *e = material_ext(s, in->off.material_offset);
+        uint32_t np = in->off.index_count / 3;
+        for (uint32_t p = 0; p < np; ++p, ++k)
+            if (light_candidate(s, e, k, &cr, &len, &area, &power)) { total += (double)power; ++n; }
+    }
+    if (!n || !(total > 0.0)) return;
+    s->lights = (light_t *)malloc(sizeof(light_t) * n);
+    double run = 0.0;
+    uint64_t li = 0;
+    k = 0;
+    for (uint64_t i = 0; i < s->d.n_instances; ++i) {
+        const orc_instance *in = &s->d.instances[i];
+        const orc_material_ext *e = material_ext(s, in->off.material_offset);
+        uint32_t np = in->off.index_count / 3;
+        for (uint32_t p = 0; p < np; ++p, ++k) {
+            if (!light_candidate(s, e, k, &cr, &len, &area, &power)) continue;
+            const wtri *t = &s->tris[k];
+            run += (double)power;
+            light_t *l = &s->lights[li++];
+            l->a = t->a; l->b = t->b; l->c = t->c;
+            l->n = v3_scale(cr, 1.0f / len);
+            l->le = v3_make(e->emissive[0], e->emissive[1], e->emissive[2]);
+            l->cdf = (float)(run / total);
+            l->pdf_area = (float)((double)power / total) / area;
+        }
+    }
+    s->lights[li - 1].cdf = 1.0f;
+    s->n_lights = li;
+}
+
+uint64_t orc_scene_light_count(const orc_scene *s) { return s->n_lights; }
+void orc_scene_light(const orc_scene *s, uint64_t i, float verts[9], float le[3], float *cdf, float *pdf_area)
+{
+    const light_t *l = &s->lights[i];
+    verts[0] = l->a.x; verts[1] = l->a.y; verts[2] = l->a.z; verts[3] = l->b.x; verts[4] = l->b.y; verts[5] = l->b.z;
+    verts[6] = l->c.x; verts[7] = l->c.y; verts[8] = l->c.z;
+    le[0] = l->le.x; le[1] = l->le.y; le[2] = l->le.z; *cdf = l->cdf; *pdf_area = l->pdf_area;
+}
+
 orc_scene *orc_scene_create(const orc_scene_desc *desc)
 {
     pthread_once(&g_lut_once, init_lut);
@@ -409,10 +504,14 @@ orc_scene *orc_scene_create(const orc_scene_desc *desc)
     for (uint64_t i = 0; i < desc->n_instances; ++i) nt += desc->instances[i].off.index_count / 3;
     s->n_tris = nt;
     s->tris = (wtri *)malloc(sizeof(wtri) * (nt ? nt : 1));
+    s->inst_first = (uint64_t *)malloc(sizeof(uint64_t) * (desc->n_instances ? desc->n_instances : 1));
+    s->cof = (float (*)[9])malloc(sizeof(float[9]) * (desc->n_instances ? desc->n_instances : 1));
     uint64_t k = 0;
     for (uint64_t i = 0; i < desc->n_instances; ++i) {
         const orc_instance *in = &desc->instances[i];
         uint32_t np = in->off.index_count / 3;
+        s->inst_first[i] = k;
+        normal_matrix(in->xform, s->cof[i]);
         for (uint32_t p = 0; p < np; ++p) {
             const uint32_t *ix = &desc->indices[in->off.index_offset + (uint64_t)p * 3];
             const orc_vertex *v0 = &desc->vertices[in->off.vertex_offset + ix[0]];
@@ -425,6 +524,7 @@ orc_scene *orc_scene_create(const orc_scene_desc *desc)
             t->instance = (uint32_t)i; t->prim = p;
         }
     }
+    build_lights(s);
     if (nt > 64) {
         s->order = (uint32_t *)malloc(sizeof(uint32_t) * nt);
         for (uint64_t i = 0; i < nt; ++i) s->order[i] = (uint32_t)i;
@@ -442,7 +542,7 @@ orc_scene *orc_scene_create(const orc_scene_desc *desc)
 void orc_scene_destroy(orc_scene *s)
 {
     if (!s) return;
-    free(s->tris); free(s->order); free(s->nodes); free(s);
+    free(s->tris); free(s->order); free(s->nodes); free(s->inst_first); free(s->cof); free(s->lights); free(s);
 }
 
 uint64_t orc_scene_triangle_count(const orc_scene *s) { return s->n_tris; }
@@ -472,6 +572,7 @@ static void miss_shader(payload_t *pl, v3 ray_dir)
  * LOD 0 (graphics.rs:453-459, parity unpinned); texel = clamp(floor(u*W),0,W-1) */
 static v3 sample_texture(const orc_texture *tx, float u, float v)
 {
+    if (tx->srgb & 2u) { u = u - floorf(u); v = v - floorf(v); }   /* build extension: wrap = repeat */
     float fu = floorf(u * (float)tx->width), fv = floorf(v * (float)tx->height);
     float mu = (float)(tx->width - 1), mv = (float)(tx->height - 1);
     if (!(fu >= 0.0f)) fu = 0.0f;
@@ -479,7 +580,7 @@ static v3 sample_texture(const orc_texture *tx, float u, float v)
     if (!(fv >= 0.0f)) fv = 0.0f;
     if (fv > mv) fv = mv;
     const uint8_t *px = tx->rgba8 + ((uint64_t)(uint32_t)fv * tx->width + (uint32_t)fu) * 4;
-    if (tx->srgb) return v3_make(g_srgb_lut[px[0]], g_srgb_lut[px[1]], g_srgb_lut[px[2]]);
+    if (tx->srgb & 1u) return v3_make(g_srgb_lut[px[0]], g_srgb_lut[px[1]], g_srgb_lut[px[2]]);
     return v3_make((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
 }
 
@@ -499,6 +600,11 @@ static void closest_hit_shader(const orc_scene *s, payload_t *pl, const hit_rec 
     v3 n0 = v3_make(v0->normal[0], v0->normal[1], v0->normal[2]);
     v3 n1 = v3_make(v1->normal[0], v1->normal[1], v1->normal[2]);
     v3 n2 = v3_make(v2->normal[0], v2->normal[1], v2->normal[2]);
+    if (d->options & ORC_SCENE_WORLD_NORMALS) {     /* build extension; the reference keeps object space */
+        n0 = normal_to_world(s->cof[h->instance], n0);
+        n1 = normal_to_world(s->cof[h->instance], n1);
+        n2 = normal_to_world(s->cof[h->instance], n2);
+    }
     /* :175-179  object-space normal, never transformed, never flipped */
     v3 normal = v3_normalize(v3_add(v3_add(v3_scale(n0, bx), v3_scale(n1, by)), v3_scale(n2, bz)));
     float tu = (v0->uv[0] * bx + v1->uv[0] * by) + v2->uv[0] * bz;      /* :180-183 */
@@ -510,6 +616,8 @@ static void closest_hit_shader(const orc_scene *s, payload_t *pl, const hit_rec 
     v3 albedo;
     if (m->has_base_texture) {                                          /* :193-198 */
         albedo = sample_texture(&d->textures[m->base_texture_indice], tu, tv);
+        if (d->options & ORC_SCENE_TEXTURE_TIMES_FACTOR)
+            albedo = v3_mul(albedo, v3_make(m->base_color[0], m->base_color[1], m->base_color[2]));
         if (st) st->textured_hits++;
     } else {
         albedo = v3_make(m->base_color[0], m->base_color[1], m->base_color[2]);
@@ -636,6 +744,300 @@ static void raygen_pixel(job_t *j, uint32_t x, uint32_t y)
     j->st.samples++;
 }
 
+/* ------------------------------------------------------------------ */
+/* Lit integrator (build extension; todo.md:4 "Proper lighting", the Russian-roulette
+ * sketch of rchit.glsl:256-265).  NOT a restatement of reference code: the reference has no light
+ * sources beyond its sky.  This is the specification the HIP stages k_shade_lit / k_shadow_resolve
+ * implement, expression for expression:
+ *   - radiance L accumulated per path: sky on a miss, emission when a camera ray or a specular
+ *     bounce hits an emitter (emitters reached by a sampled diffuse / glossy bounce are covered by
+ *     next-event estimation instead);
+ *   - next-event estimation at every opaque hit: one emissive triangle picked by area x luminance,
+ *     one uniformly sampled point, one occlusion query;
+ *   - BSDF: glTF metallic-roughness = Lambert + GGX (VNDF sampling, Smith separable G, Schlick F),
+ *     one-sample lobe choice weighted with the mixture pdf; KHR_materials_transmission = smooth
+ *     dielectric (Schlick Fresnel, Snell refraction);
+ *   - Russian roulette from the fourth bounce on.
+ * Random numbers: rand() of shared.glsl:194-207 with per-dimension seed offsets. */
+#define LIT_SEED_LOBE 101u
+#define LIT_SEED_MIX 151u
+#define LIT_SEED_LIGHT 211u
+#define LIT_SEED_LU 307u
+#define LIT_SEED_LV 401u
+#define LIT_SEED_RR 503u
+#define LIT_SEED_U1 7919u
+#define LIT_SEED_U2 16381u
+#define LIT_INV_PI 0.318309886f
+#define LIT_SHADOW_TMAX 0.999f
+
+static inline float ggx_d(float noh, float a2)
+{
+    float d = (noh * noh) * (a2 - 1.0f) + 1.0f;
+    return a2 / ((3.14159265f * d) * d);
+}
+static inline float smith_g1(float nox, float a2)
+{
+    return (2.0f * nox) / (nox + sqrtf(a2 + (1.0f - a2) * (nox * nox)));
+}
+static inline float pow5(float x) { float x2 = x * x; return (x2 * x2) * x; }
+
+/* f (rgb) and the mixture pdf of the opaque BSDF for unit wo, wi on the side of N */
+static int bsdf_eval(v3 n, v3 wo, v3 wi, v3 diff, v3 f0, float a2, float p_spec, v3 *f, float *pdf)
+{
+    float nol = v3_dot(n, wi), nov = v3_dot(n, wo);
+    if (!(nol > 0.0f && nov > 0.0f)) return 0;
+    v3 h = v3_normalize(v3_add(wo, wi));
+    float noh = v3_dot(n, h), voh = v3_dot(wo, h);
+    float dd = ggx_d(noh, a2), g1v = smith_g1(nov, a2), g1l = smith_g1(nol, a2);
+    float x = 1.0f - voh;
+    if (x < 0.0f) x = 0.0f;
+    float fr = pow5(x);
+    float spec = (dd * (g1v * g1l)) / ((4.0f * nov) * nol);
+    f->x = diff.x * LIT_INV_PI + (f0.x + (1.0f - f0.x) * fr) * spec;
+    f->y = diff.y * LIT_INV_PI + (f0.y + (1.0f - f0.y) * fr) * spec;
+    f->z = diff.z * LIT_INV_PI + (f0.z + (1.0f - f0.z) * fr) * spec;
+    *pdf = p_spec * ((dd * g1v) / (4.0f * nov)) + (1.0f - p_spec) * (nol * LIT_INV_PI);
+    return 1;
+}
+
+/* Heitz 2018, "Sampling the GGX Distribution of Visible Normals": half vector in world space */
+static v3 ggx_sample_vndf(v3 n, v3 wo, float alpha, float u1, float u2)
+{
+    v3 t, b;
+    create_basis(n, &t, &b);
+    v3 vl = v3_make(v3_dot(wo, t), v3_dot(wo, b), v3_dot(wo, n));
+    v3 vh = v3_normalize(v3_make(alpha * vl.x, alpha * vl.y, vl.z));
+    float lensq = vh.x * vh.x + vh.y * vh.y;
+    v3 t1 = v3_make(1.0f, 0.0f, 0.0f);
+    if (lensq > 0.0f) { float il = 1.0f / sqrtf(lensq); t1 = v3_make(-vh.y * il, vh.x * il, 0.0f); }
+    v3 t2 = v3_cross(vh, t1);
+    float r = sqrtf(u1), phi = 6.283185307f * u2, sn, cs;
+    orc_sincos(phi, &sn, &cs);
+    float p1 = r * cs, p2 = r * sn;
+    float sw = 0.5f * (1.0f + vh.z);
+    float om = 1.0f - p1 * p1;
+    p2 = (1.0f - sw) * sqrtf(0.0f < om ? om : 0.0f) + sw * p2;
+    float oz = (1.0f - p1 * p1) - p2 * p2;
+    float pz = sqrtf(0.0f < oz ? oz : 0.0f);
+    v3 nh = v3_add(v3_add(v3_scale(t1, p1), v3_scale(t2, p2)), v3_scale(vh, pz));
+    v3 ne = v3_normalize(v3_make(alpha * nh.x, alpha * nh.y, 0.0f < nh.z ? nh.z : 0.0f));
+    return v3_add(v3_add(v3_scale(t, ne.x), v3_scale(b, ne.y)), v3_scale(n, ne.z));
+}
+
+static inline float lit_rand(const float uv[2], uint32_t depth, uint32_t acc, uint32_t seed, uint32_t dim)
+{
+    return orc_rand(uv[0], uv[1], depth, acc, seed + dim);
+}
+
+static void raygen_pixel_lit(job_t *j, uint32_t x, uint32_t y)
+{
+    const orc_params *p = &j->p;
+    const orc_scene *s = j->s;
+    const orc_scene_desc *d = &s->d;
+    uint32_t W = j->W, H = j->H, acc = j->acc, rng_acc = acc + p->rng_sample_offset, seed = j->u.seed;
+    float pcx = (float)x + 0.5f, pcy = (float)(H - y - 1) + 0.5f;
+    float uv[2] = { pcx / (float)W, pcy / (float)H };
+    float dx = uv[0] * 2.0f - 1.0f, dy = uv[1] * 2.0f - 1.0f;
+    v3 o = mat4_mul_dir4(j->cam->view_inverse, 0.0f, 0.0f, 0.0f, 1.0f, NULL);
+    v3 target = mat4_mul_dir4(j->cam->proj_inverse, dx, dy, 1.0f, 1.0f, NULL);
+    v3 tn = v3_normalize(target);
+    v3 dir = v3_normalize(mat4_mul_dir4(j->cam->view_inverse, tn.x, tn.y, tn.z, 0.0f, NULL));
+    uint64_t pix = (uint64_t)y * W + x;
+
+    v3 L = v3_make(0.0f, 0.0f, 0.0f), thr = v3_make(1.0f, 1.0f, 1.0f);
+    int spec = 1;
+    for (uint32_t depth = 0;; ) {
+        hit_rec h;
+        int hit = trace(s, o, dir, p->t_min, p->t_max, p->flags, &h, &j->st);
+        j->st.rays++;
+        v3 gb_normal = v3_make(0.0f, 0.0f, 0.0f);
+        float gb_dist = 3.402823466e+38f;
+        int done = 0;
+        v3 new_o = o, new_d = dir;
+        if (!hit) {
+            L = v3_add(L, v3_mul(thr, sky_color(dir)));
+            done = 1;
+        } else {
+            j->st.hits++;
+            const orc_offsets *off = &d->instances[h.instance].off;
+            uint64_t ib = (uint64_t)off->index_offset + (uint64_t)h.prim * 3;
+            const orc_vertex *v0 = &d->vertices[off->vertex_offset + d->indices[ib]];
+            const orc_vertex *v1 = &d->vertices[off->vertex_offset + d->indices[ib + 1]];
+            const orc_vertex *v2 = &d->vertices[off->vertex_offset + d->indices[ib + 2]];
+            const wtri *wt = &s->tris[s->inst_first[h.instance] + h.prim];
+            float bx = 1.0f - h.u - h.v, by = h.u, bz = h.v;
+            v3 n0 = v3_make(v0->normal[0], v0->normal[1], v0->normal[2]);
+            v3 n1 = v3_make(v1->normal[0], v1->normal[1], v1->normal[2]);
+            v3 n2 = v3_make(v2->normal[0], v2->normal[1], v2->normal[2]);
+            if (d->options & ORC_SCENE_WORLD_NORMALS) {
+                n0 = normal_to_world(s->cof[h.instance], n0);
+                n1 = normal_to_world(s->cof[h.instance], n1);
+                n2 = normal_to_world(s->cof[h.instance], n2);
+            }
+            v3 ns = v3_normalize(v3_add(v3_add(v3_scale(n0, bx), v3_scale(n1, by)), v3_scale(n2, bz)));
+            v3 ng = v3_normalize(v3_cross(v3_sub(wt->b, wt->a), v3_sub(wt->c, wt->a)));
+            int front = 1;
+            if (v3_dot(ng, dir) > 0.0f) { ng = v3_scale(ng, -1.0f); front = 0; }
+            if (v3_dot(ns, ng) < 0.0f) ns = v3_scale(ns, -1.0f);
+            float tu = (v0->uv[0] * bx + v1->uv[0] * by) + v2->uv[0] * bz;
+            float tv = (v0->uv[1] * bx + v1->uv[1] * by) + v2->uv[1] * bz;
+            v3 P = v3_add(o, v3_scale(dir, h.t));
+            const orc_material *m = &d->materials[off->material_offset];
+            const orc_material_ext *e = material_ext(s, off->material_offset);
+            v3 albedo = v3_make(m->base_color[0], m->base_color[1], m->base_color[2]);
+            if (m->has_base_texture) {
+                albedo = v3_mul(sample_texture(&d->textures[m->base_texture_indice], tu, tv), albedo);
+                j->st.textured_hits++;
+            }
+            v3 wo = v3_scale(dir, -1.0f);
+            v3 up_o = v3_add(P, v3_scale(ng, p->normal_eps));
+            gb_normal = ns;
+            gb_dist = v3_length(v3_sub(up_o, o));
+
+            if (spec && (e->emissive[0] > 0.0f || e->emissive[1] > 0.0f || e->emissive[2] > 0.0f))
+                L = v3_add(L, v3_mul(thr, v3_make(e->emissive[0], e->emissive[1], e->emissive[2])));
+
+            float u_lobe = lit_rand(uv, depth, rng_acc, seed, LIT_SEED_LOBE);
+            float u1 = lit_rand(uv, depth, rng_acc, seed, LIT_SEED_U1);
+            float u2 = lit_rand(uv, depth, rng_acc, seed, LIT_SEED_U2);
+            if (e->transmission > 0.0f && u_lobe < e->transmission) {
+                /* smooth dielectric */
+                float ior = e->ior;
+                float eta = front ? 1.0f / ior : ior;
+                float cosi = v3_dot(wo, ns);
+                if (cosi < 0.0f) cosi = 0.0f;
+                if (cosi > 1.0f) cosi = 1.0f;
+                float sin2t = (eta * eta) * (1.0f - cosi * cosi);
+                int reflect = 1;
+                float cost = 0.0f;
+                if (sin2t < 1.0f) {
+                    cost = sqrtf(1.0f - sin2t);
+                    float r0 = (1.0f - ior) / (1.0f + ior);
+                    r0 = r0 * r0;
+                    float c = front ? cosi : cost;
+                    float fr = r0 + (1.0f - r0) * pow5(1.0f - c);
+                    reflect = u1 < fr;
+                }
+                if (reflect) {
+                    new_d = v3_normalize(v3_add(dir, v3_scale(ns, 2.0f * cosi)));
+                    new_o = up_o;
+                } else {
+                    new_d = v3_normalize(v3_add(v3_scale(dir, eta), v3_scale(ns, eta * cosi - cost)));
+                    new_o = v3_sub(P, v3_scale(ng, p->normal_eps));
+                    thr = v3_mul(thr, albedo);
+                }
+                spec = 1;
+            } else {
+                float rough = m->roughness, metal = m->metallic;
+                float alpha = rough * rough;
+                if (alpha < 0.0025f) alpha = 0.0025f;
+                float a2 = alpha * alpha;
+                float om = 1.0f - metal;
+                v3 f0 = v3_make(0.04f * om + albedo.x * metal, 0.04f * om + albedo.y * metal, 0.04f * om + albedo.z * metal);
+                v3 diff = v3_scale(albedo, om);
+                float p_spec = 0.25f + 0.75f * metal;
+
+                /* next-event estimation */
+                if (s->n_lights) {
+                    float ul = lit_rand(uv, depth, rng_acc, seed, LIT_SEED_LIGHT);
+                    uint64_t lo = 0, hi = s->n_lights;
+                    while (lo < hi) { uint64_t mid = (lo + hi) / 2; if (s->lights[mid].cdf <= ul) lo = mid + 1; else hi = mid; }
+                    if (lo >= s->n_lights) lo = s->n_lights - 1;
+                    const light_t *l = &s->lights[lo];
+                    float a = lit_rand(uv, depth, rng_acc, seed, LIT_SEED_LU);
+                    float b = lit_rand(uv, depth, rng_acc, seed, LIT_SEED_LV);
+                    float su = sqrtf(a);
+                    float w0 = 1.0f - su, w1 = su * (1.0f - b), w2 = su * b;
+                    v3 pl = v3_add(v3_add(v3_scale(l->a, w0), v3_scale(l->b, w1)), v3_scale(l->c, w2));
+                    v3 dl = v3_sub(pl, up_o);
+                    float dist2 = v3_dot(dl, dl);
+                    float inv_dist = 1.0f / sqrtf(dist2);
+                    v3 wl = v3_scale(dl, inv_dist);
+                    float cos_g = v3_dot(ng, wl);
+                    float cos_l = fabsf(v3_dot(l->n, wl));
+                    v3 f; float pdf_unused;
+                    if (dist2 > 0.0f && cos_g > 0.0f && cos_l > 0.0f && bsdf_eval(ns, wo, wl, diff, f0, a2, p_spec, &f, &pdf_unused)) {
+                        float cos_s = v3_dot(ns, wl);
+                        float gterm = (cos_s * cos_l) / (dist2 * l->pdf_area);
+                        v3 c = v3_scale(v3_mul(v3_mul(thr, f), l->le), gterm);
+                        hit_rec sh;
+                        j->st.shadow_rays++;
+                        if (!trace(s, up_o, dl, p->t_min, LIT_SHADOW_TMAX, p->flags, &sh, &j->st))
+                            L = v3_add(L, c);
+                    }
+                }
+
+                /* sample the next direction */
+                float u_mix = lit_rand(uv, depth, rng_acc, seed, LIT_SEED_MIX);
+                v3 wi;
+                if (u_mix < p_spec) {
+                    v3 hv = ggx_sample_vndf(ns, wo, alpha, u1, u2);
+                    wi = v3_normalize(v3_sub(v3_scale(hv, 2.0f * v3_dot(wo, hv)), wo));
+                } else {
+                    float r = sqrtf(u1), phi = 6.283185307f * u2, sn, cs;
+                    orc_sincos(phi, &sn, &cs);
+                    float lx = r * cs, ly = r * sn, oz = 1.0f - u1;
+                    float lz = sqrtf(0.0f < oz ? oz : 0.0f);
+                    v3 t, b;
+                    create_basis(ns, &t, &b);
+                    wi = v3_normalize(v3_add(v3_add(v3_scale(t, lx), v3_scale(b, ly)), v3_scale(ns, lz)));
+                }
+                v3 f; float pdf;
+                if (v3_dot(wi, ng) > 0.0f && bsdf_eval(ns, wo, wi, diff, f0, a2, p_spec, &f, &pdf) && pdf > 0.0f) {
+                    float wgt = v3_dot(ns, wi) / pdf;
+                    thr = v3_mul(thr, v3_scale(f, wgt));
+                    new_d = wi;
+                    new_o = up_o;
+                } else {
+                    done = 1;
+                }
+                spec = 0;
+            }
+            /* Russian roulette (rchit.glsl:256-265 sketches one; this one is unbiased) */
+            if (!done && depth >= 3) {
+                float pr = fmaxf(thr.x, fmaxf(thr.y, thr.z));
+                if (pr > 1.0f) pr = 1.0f;
+                if (pr < 0.05f) pr = 0.05f;
+                if (lit_rand(uv, depth, rng_acc, seed, LIT_SEED_RR) >= pr) done = 1;
+                else thr = v3_scale(thr, 1.0f / pr);
+            }
+            if (!done && !(finite3(thr) && finite3(new_d))) done = 1;
+        }
+
+        if (depth == 0) {
+            if (j->ids && acc == j->u.accumulated_count) {
+                j->ids[pix * 2 + 0] = hit ? h.instance : 0xFFFFFFFFu;
+                j->ids[pix * 2 + 1] = hit ? h.prim : 0xFFFFFFFFu;
+            }
+            if (acc == 0) {
+                float z_range = j->u.z_far - j->u.z_near;
+                float zn = (gb_dist - j->u.z_near) / z_range;
+                zn = fminf(fmaxf(zn, 0.0f), 1.0f);
+                if (j->depth) j->depth[pix] = zn;
+                if (j->normal) {
+                    j->normal[pix * 4 + 0] = gb_normal.x; j->normal[pix * 4 + 1] = gb_normal.y;
+                    j->normal[pix * 4 + 2] = gb_normal.z; j->normal[pix * 4 + 3] = 1.0f;
+                }
+            }
+        }
+        depth++;
+        if (done || depth >= p->max_depth) break;
+        o = new_o; dir = new_d;
+    }
+
+    /* rgen.glsl:124-141 running mean, with the radiance in place of the attenuation product */
+    float n = (float)acc;
+    float *px = &j->albedo[pix * 4];
+    v3 cur = v3_make(px[0], px[1], px[2]);
+    v3 scaled_cur = v3_make(cur.x * n / (n + 1.0f), cur.y * n / (n + 1.0f), cur.z * n / (n + 1.0f));
+    v3 scaled_att = v3_make(L.x / (n + 1.0f), L.y / (n + 1.0f), L.z / (n + 1.0f));
+    px[0] = scaled_att.x + scaled_cur.x;
+    px[1] = scaled_att.y + scaled_cur.y;
+    px[2] = scaled_att.z + scaled_cur.z;
+    px[3] = 1.0f;
+    j->st.samples++;
+}
+
 typedef struct { job_t *jobs; uint32_t n_bands, t, nt; } band_arg;
 
 /* static round-robin assignment of row bands to threads */
@@ -645,8 +1047,10 @@ static void *thread_bands(void *arg)
     for (uint32_t b = a->t; b < a->n_bands; b += a->nt) {
         job_t *j = &a->jobs[b];
         for (uint32_t y = j->y0; y < j->y1; ++y)
-            for (uint32_t x = 0; x < j->W; ++x)
-                raygen_pixel(j, x, y);
+            for (uint32_t x = 0; x < j->W; ++x) {
+                if (j->p.integrator == ORC_INTEGRATOR_LIT) raygen_pixel_lit(j, x, y);
+                else raygen_pixel(j, x, y);
+            }
     }
     return NULL;
 }
@@ -681,6 +1085,7 @@ void orc_render(const orc_scene *s, const orc_camera *cam, const orc_uniforms *u
             total.rays += jobs[b].st.rays; total.hits += jobs[b].st.hits; total.samples += jobs[b].st.samples;
             total.textured_hits += jobs[b].st.textured_hits;
             total.nodes_visited += jobs[b].st.nodes_visited; total.tris_tested += jobs[b].st.tris_tested;
+            total.shadow_rays += jobs[b].st.shadow_rays;
         }
         free(ta); free(jobs);
     }

@@ -72,9 +72,27 @@ typedef struct {
 typedef struct {
     const uint8_t *rgba8;   /* W*H*4, row 0 first */
     uint32_t width, height;
-    uint32_t srgb;          /* 1: R8G8B8A8_SRGB (graphics.rs:494-495) */
+    uint32_t srgb;          /* bit0: R8G8B8A8_SRGB (graphics.rs:494-495); bit1 (build extension):
+                               wrap = repeat instead of the reference's clamp-to-edge */
     uint32_t _pad;
 } orc_texture;
+
+/* Build extension (todo.md:4 "Proper lighting"): material properties the
+ * reference's Material (material.rs:70-76) does not carry.  One row per material, same index. */
+typedef struct {
+    float emissive[3];      /* glTF emissiveFactor x KHR_materials_emissive_strength (linear radiance) */
+    float transmission;     /* KHR_materials_transmission: probability of the smooth dielectric lobe */
+    float ior;              /* KHR_materials_ior (1.5) */
+    uint32_t _pad[3];
+} orc_material_ext;
+
+/* scene options (orc_scene_desc.options); 0 = the reference's behaviour, quirks included */
+#define ORC_SCENE_WORLD_NORMALS 1u        /* normals taken to world space by the inverse transpose (rchit.glsl:175-179 does not) */
+#define ORC_SCENE_TEXTURE_TIMES_FACTOR 2u /* albedo = texel * baseColorFactor (rchit.glsl:193-195 drops the factor) */
+
+/* orc_params.integrator */
+#define ORC_INTEGRATOR_REFERENCE 0u
+#define ORC_INTEGRATOR_LIT 1u             /* emissive triangles + next-event estimation + metallic-roughness / glass BSDFs */
 
 /* constants hard-coded in the reference, exposed as parameters */
 typedef struct {
@@ -84,7 +102,8 @@ typedef struct {
     float normal_eps;           /* rchit.glsl:242 (0.001) */
     uint32_t rng_sample_offset; /* added to accumulated_count for the RNG only (spp partition) */
     uint32_t flags;             /* bit0: force brute-force closest hit */
-    uint32_t _pad[2];
+    uint32_t integrator;        /* ORC_INTEGRATOR_* */
+    uint32_t _pad;
 } orc_params;
 
 typedef struct {
@@ -93,6 +112,8 @@ typedef struct {
     const orc_material *materials; uint64_t n_materials;
     const orc_instance *instances; uint64_t n_instances;
     const orc_texture *textures;   uint64_t n_textures;
+    const orc_material_ext *material_ext;   /* n_materials rows, or NULL: no emission, no transmission */
+    uint64_t options;                       /* ORC_SCENE_* */
 } orc_scene_desc;
 
 typedef struct orc_scene orc_scene;
@@ -103,6 +124,7 @@ typedef struct {
     uint64_t samples;   /* pixel-samples rendered */
     uint64_t textured_hits;
     uint64_t nodes_visited, tris_tested;
+    uint64_t shadow_rays;   /* lit integrator: occlusion queries (not counted in rays) */
 } orc_stats;
 
 void orc_default_params(orc_params *p);
@@ -126,6 +148,11 @@ void orc_render(const orc_scene *s, const orc_camera *cam, const orc_uniforms *u
                 const orc_params *p, uint32_t width, uint32_t height, uint32_t n_samples,
                 float *albedo, float *normal, float *depth, uint32_t *primary_ids,
                 orc_stats *stats, int n_threads);
+
+/* lit integrator: number of emissive triangles in the light table, and row i of it
+ * (9 floats of world-space vertices, 3 of radiance, cdf, pdf per unit area) for the tests */
+uint64_t orc_scene_light_count(const orc_scene *s);
+void orc_scene_light(const orc_scene *s, uint64_t i, float verts[9], float le[3], float *cdf, float *pdf_area);
 
 /* closest hit for one ray (brute force if flags bit0). Returns 1 on hit. */
 int orc_trace(const orc_scene *s, const float org[3], const float dir[3], float t_min, float t_max,

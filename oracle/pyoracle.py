@@ -9,7 +9,7 @@ import subprocess
 
 import numpy as np
 
-from .gltf_ingest import INSTANCE_DTYPE, MATERIAL_DTYPE, VERTEX_DTYPE
+from .gltf_ingest import INSTANCE_DTYPE, MATERIAL_DTYPE, MATERIAL_EXT_DTYPE, VERTEX_DTYPE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libpt_oracle.so")
@@ -35,7 +35,11 @@ class Uniforms(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("max_depth", C.c_uint32), ("t_min", C.c_float), ("t_max", C.c_float), ("normal_eps", C.c_float),
-                ("rng_sample_offset", C.c_uint32), ("flags", C.c_uint32), ("_pad", C.c_uint32 * 2)]
+                ("rng_sample_offset", C.c_uint32), ("flags", C.c_uint32), ("integrator", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+INTEGRATOR_REFERENCE, INTEGRATOR_LIT = 0, 1
+SCENE_WORLD_NORMALS, SCENE_TEXTURE_TIMES_FACTOR = 1, 2
 
 
 class Texture(C.Structure):
@@ -48,12 +52,13 @@ class SceneDesc(C.Structure):
                 ("indices", C.c_void_p), ("n_indices", C.c_uint64),
                 ("materials", C.c_void_p), ("n_materials", C.c_uint64),
                 ("instances", C.c_void_p), ("n_instances", C.c_uint64),
-                ("textures", C.c_void_p), ("n_textures", C.c_uint64)]
+                ("textures", C.c_void_p), ("n_textures", C.c_uint64),
+                ("material_ext", C.c_void_p), ("options", C.c_uint64)]
 
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("hits", C.c_uint64), ("samples", C.c_uint64), ("textured_hits", C.c_uint64),
-                ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64)]
+                ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("shadow_rays", C.c_uint64)]
 
 
 _lib = None
@@ -73,6 +78,10 @@ def lib():
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Uniforms), C.POINTER(Params),
                                  C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.POINTER(Stats), C.c_int]
+        L.orc_scene_light_count.restype = C.c_uint64
+        L.orc_scene_light_count.argtypes = [C.c_void_p]
+        L.orc_scene_light.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_trace.restype = C.c_int
         L.orc_trace.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float,
                                 C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
@@ -133,7 +142,7 @@ def yaw_quat(yaw_deg):
 class OracleScene:
     """Owns the numpy arrays an orc_scene points into."""
 
-    def __init__(self, vertices, indices, materials, instances, textures=()):
+    def __init__(self, vertices, indices, materials, instances, textures=(), material_ext=None, options=0):
         self.vertices = np.ascontiguousarray(vertices, dtype=VERTEX_DTYPE)
         self.indices = np.ascontiguousarray(indices, dtype=np.uint32)
         self.materials = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
@@ -142,9 +151,14 @@ class OracleScene:
         self.tex_structs = (Texture * max(1, len(textures)))()
         for i, (rgba, srgb) in enumerate(textures):
             self.tex_structs[i] = Texture(self.tex_arrays[i].ctypes.data, rgba.shape[1], rgba.shape[0], int(srgb), 0)
+        self.material_ext = None
+        if material_ext is not None:
+            self.material_ext = np.ascontiguousarray(material_ext, dtype=MATERIAL_EXT_DTYPE)
+            assert len(self.material_ext) == len(self.materials)
         d = SceneDesc(self.vertices.ctypes.data, len(self.vertices), self.indices.ctypes.data, len(self.indices),
                       self.materials.ctypes.data, len(self.materials), self.instances.ctypes.data,
-                      len(self.instances), C.addressof(self.tex_structs), len(textures))
+                      len(self.instances), C.addressof(self.tex_structs), len(textures),
+                      self.material_ext.ctypes.data if self.material_ext is not None else None, options)
         self.handle = lib().orc_scene_create(C.byref(d))
 
     def __del__(self):
@@ -174,6 +188,17 @@ class OracleScene:
         return dict(albedo=albedo, normal=normal, depth=depth, ids=ids,
                     stats={k: getattr(st, k) for k, _ in Stats._fields_})
 
+    def lights(self):
+        """The lit integrator's light table: list of (verts 3x3, le 3, cdf, pdf_area)."""
+        out = []
+        for i in range(lib().orc_scene_light_count(self.handle)):
+            v = np.zeros(9, np.float32)
+            le = np.zeros(3, np.float32)
+            cdf, pdf = C.c_float(), C.c_float()
+            lib().orc_scene_light(self.handle, i, _fp(v), _fp(le), C.byref(cdf), C.byref(pdf))
+            out.append((v.reshape(3, 3), le, cdf.value, pdf.value))
+        return out
+
     def trace(self, org, dirv, t_min=0.001, t_max=10000.0, flags=0):
         t, u, v = C.c_float(), C.c_float(), C.c_float()
         inst, prim = C.c_uint32(), C.c_uint32()
@@ -182,7 +207,8 @@ class OracleScene:
         return (t.value, u.value, v.value, inst.value, prim.value) if hit else None
 
 
-def scene_from_ingest(ing):
+def scene_from_ingest(ing, options=0, with_material_ext=False):
     """IngestedScene -> OracleScene with the reference's per-entity instance list."""
     inst = ing.instances(transform_matrix)
-    return OracleScene(ing.vertices, ing.indices, ing.materials, inst, ing.textures)
+    return OracleScene(ing.vertices, ing.indices, ing.materials, inst, ing.textures,
+                       material_ext=ing.material_ext if with_material_ext else None, options=options)

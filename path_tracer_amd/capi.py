@@ -12,6 +12,9 @@ LIB_PATH = os.path.join(_HERE, "libptx_amd.so")
 
 PTX_OK, PTX_ERR_INVALID, PTX_ERR_CAPACITY, PTX_ERR_HIP, PTX_ERR_STATE = range(5)
 IMAGE_ALBEDO, IMAGE_NORMAL, IMAGE_DEPTH, IMAGE_PRIMARY_ID = range(4)
+INTEGRATOR_REFERENCE, INTEGRATOR_LIT = 0, 1
+SCENE_WORLD_NORMALS, SCENE_TEXTURE_TIMES_FACTOR = 1, 2
+TEXTURE_SRGB, TEXTURE_REPEAT = 1, 2
 
 VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("_p0", "<f4"), ("normal", "<f4", 3), ("_p1", "<f4"),
                          ("uv", "<f4", 2), ("padding", "<f4", 2)])
@@ -20,6 +23,7 @@ MATERIAL_DTYPE = np.dtype([("base_color", "<f4", 4), ("has_base_texture", "<u4")
 OFFSETS_DTYPE = np.dtype([("vertex_offset", "<u4"), ("vertex_count", "<u4"), ("material_offset", "<u4"),
                           ("padding", "<u4"), ("index_offset", "<u4"), ("index_count", "<u4")])
 INSTANCE_DTYPE = np.dtype([("xform", "<f4", (3, 4)), ("geometry", "<u4"), ("off", OFFSETS_DTYPE)])
+MATERIAL_EXT_DTYPE = np.dtype([("emissive", "<f4", 3), ("transmission", "<f4"), ("ior", "<f4"), ("_pad", "<u4", 3)])
 
 
 class Camera(C.Structure):
@@ -33,7 +37,7 @@ class Uniforms(C.Structure):
 
 class RenderParams(C.Structure):
     _fields_ = [("max_depth", C.c_uint32), ("t_min", C.c_float), ("t_max", C.c_float), ("normal_eps", C.c_float),
-                ("rng_sample_offset", C.c_uint32), ("flags", C.c_uint32), ("_pad", C.c_uint32 * 2)]
+                ("rng_sample_offset", C.c_uint32), ("flags", C.c_uint32), ("integrator", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class Limits(C.Structure):
@@ -46,7 +50,8 @@ class Stats(C.Structure):
                 ("extend_launches", C.c_uint64), ("extend_ms", C.c_double), ("shade_ms", C.c_double),
                 ("total_ms", C.c_double), ("bvh_nodes", C.c_uint64), ("bvh_triangles", C.c_uint64),
                 ("bvh_bytes", C.c_uint64), ("bvh_depth", C.c_uint32), ("_pad", C.c_uint32),
-                ("nodes_fetched", C.c_uint64), ("tris_tested", C.c_uint64), ("wave_sched", C.c_uint64 * 6)]
+                ("nodes_fetched", C.c_uint64), ("tris_tested", C.c_uint64), ("wave_sched", C.c_uint64 * 6),
+                ("shadow_rays", C.c_uint64), ("lights", C.c_uint64)]
 
 
 EXPORTS = [
@@ -55,6 +60,7 @@ EXPORTS = [
     "ptx_set_instances", "ptx_resize", "ptx_render", "ptx_render_batch", "ptx_read_image", "ptx_write_albedo",
     "ptx_export_albedo_device", "ptx_import_albedo_device", "ptx_reduce_accumulation", "ptx_synchronize",
     "ptx_set_profiling", "ptx_get_stats", "ptx_reset_stats", "ptx_last_error",
+    "ptx_set_material_ext", "ptx_set_scene_options",
 ]
 
 _lib = None
@@ -103,6 +109,8 @@ def load():
     L.ptx_reset_stats.argtypes = [vp]
     L.ptx_last_error.argtypes = [vp]
     L.ptx_last_error.restype = C.c_char_p
+    L.ptx_set_material_ext.argtypes = [vp, C.c_uint32, vp]
+    L.ptx_set_scene_options.argtypes = [vp, C.c_uint32]
     _lib = L
     return L
 
@@ -166,12 +174,20 @@ class Context:
         return out.value
 
     def add_texture(self, rgba8, srgb=True):
+        """`srgb`: bool, or the flag word TEXTURE_SRGB | TEXTURE_REPEAT."""
         a = np.ascontiguousarray(rgba8, dtype=np.uint8)
         assert a.ndim == 3 and a.shape[2] == 4
         out = C.c_uint32()
-        self._check(self._L.ptx_add_texture(self.handle, a.ctypes.data, a.shape[1], a.shape[0], int(bool(srgb)),
+        self._check(self._L.ptx_add_texture(self.handle, a.ctypes.data, a.shape[1], a.shape[0], int(srgb),
                                             C.byref(out)))
         return out.value
+
+    def set_material_ext(self, index, ext):
+        e = np.ascontiguousarray(ext, dtype=MATERIAL_EXT_DTYPE).reshape(1)
+        self._check(self._L.ptx_set_material_ext(self.handle, index, e.ctypes.data))
+
+    def set_scene_options(self, options):
+        self._check(self._L.ptx_set_scene_options(self.handle, options))
 
     def create_geometry(self, first_vertex, n_vertices, first_index, n_indices):
         out = C.c_uint32()

@@ -204,4 +204,66 @@ PT_HD bool hit_better(float t, uint32_t inst, uint32_t prim, float bt, uint32_t 
     return (inst < bi) || (inst == bi && prim < bp);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Lit integrator (build extension): BSDF pieces.  Specified by
+// oracle/pt_oracle.c (raygen_pixel_lit and its helpers); same fp32 expression trees here.
+constexpr uint32_t kLitSeedLobe = 101u, kLitSeedMix = 151u, kLitSeedLight = 211u, kLitSeedLu = 307u,
+                   kLitSeedLv = 401u, kLitSeedRr = 503u, kLitSeedU1 = 7919u, kLitSeedU2 = 16381u;
+constexpr float kLitInvPi = 0.318309886f;
+constexpr float kLitShadowTmax = 0.999f;
+
+PT_HD float ggx_d(float noh, float a2)
+{
+    float d = (noh * noh) * (a2 - 1.0f) + 1.0f;
+    return a2 / ((3.14159265f * d) * d);
+}
+PT_HD float smith_g1(float nox, float a2)
+{
+    return (2.0f * nox) / (nox + sqrtf(a2 + (1.0f - a2) * (nox * nox)));
+}
+PT_HD float pow5(float x) { float x2 = x * x; return (x2 * x2) * x; }
+
+// f (rgb) and the mixture pdf of the opaque BSDF (Lambert + GGX) for unit wo, wi on the side of n
+PT_HD bool bsdf_eval(f3 n, f3 wo, f3 wi, f3 diff, f3 f0, float a2, float p_spec, f3 &f, float &pdf)
+{
+    float nol = dot(n, wi), nov = dot(n, wo);
+    if (!(nol > 0.0f && nov > 0.0f)) return false;
+    f3 h = normalize(wo + wi);
+    float noh = dot(n, h), voh = dot(wo, h);
+    float dd = ggx_d(noh, a2), g1v = smith_g1(nov, a2), g1l = smith_g1(nol, a2);
+    float x = 1.0f - voh;
+    if (x < 0.0f) x = 0.0f;
+    float fr = pow5(x);
+    float spec = (dd * (g1v * g1l)) / ((4.0f * nov) * nol);
+    f.x = diff.x * kLitInvPi + (f0.x + (1.0f - f0.x) * fr) * spec;
+    f.y = diff.y * kLitInvPi + (f0.y + (1.0f - f0.y) * fr) * spec;
+    f.z = diff.z * kLitInvPi + (f0.z + (1.0f - f0.z) * fr) * spec;
+    pdf = p_spec * ((dd * g1v) / (4.0f * nov)) + (1.0f - p_spec) * (nol * kLitInvPi);
+    return true;
+}
+
+// Heitz 2018 visible-normal sampling of GGX: half vector in world space
+PT_HD f3 ggx_sample_vndf(f3 n, f3 wo, float alpha, float u1, float u2)
+{
+    f3 t, b;
+    create_basis(n, t, b);
+    f3 vl = mk3(dot(wo, t), dot(wo, b), dot(wo, n));
+    f3 vh = normalize(mk3(alpha * vl.x, alpha * vl.y, vl.z));
+    float lensq = vh.x * vh.x + vh.y * vh.y;
+    f3 t1 = mk3(1.0f, 0.0f, 0.0f);
+    if (lensq > 0.0f) { float il = 1.0f / sqrtf(lensq); t1 = mk3(-vh.y * il, vh.x * il, 0.0f); }
+    f3 t2 = cross(vh, t1);
+    float r = sqrtf(u1), phi = 6.283185307f * u2, sn, cs;
+    sincos_2pi(phi, sn, cs);
+    float p1 = r * cs, p2 = r * sn;
+    float sw = 0.5f * (1.0f + vh.z);
+    float om = 1.0f - p1 * p1;
+    p2 = (1.0f - sw) * sqrtf(0.0f < om ? om : 0.0f) + sw * p2;
+    float oz = (1.0f - p1 * p1) - p2 * p2;
+    float pz = sqrtf(0.0f < oz ? oz : 0.0f);
+    f3 nh = (t1 * p1 + t2 * p2) + vh * pz;
+    f3 ne = normalize(mk3(alpha * nh.x, alpha * nh.y, 0.0f < nh.z ? nh.z : 0.0f));
+    return (t * ne.x + b * ne.y) + n * ne.z;
+}
+
 }  // namespace ptx

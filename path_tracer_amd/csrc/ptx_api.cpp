@@ -41,6 +41,8 @@ struct ptx_context {
     std::vector<ptx_vertex> vertices;
     std::vector<uint32_t> indices;
     std::vector<ptx_material> materials;
+    std::vector<ptx_material_ext> material_ext;   // build extension: one row per material
+    uint32_t scene_options = 0;                   // ptx_scene_option bits
     std::vector<Geometry> geometries;
     std::vector<TexDesc> textures;          // device texel pointers
     uint32_t n_instances = 0;
@@ -50,6 +52,9 @@ struct ptx_context {
     TriRec *d_tris = nullptr; ShadeRec *d_shade = nullptr; uint64_t n_tris = 0;
     TexDesc *d_textures = nullptr;
     float *d_lut = nullptr;
+    LitMaterial *d_lit_materials = nullptr;       // lit integrator
+    LightRec *d_lights = nullptr; float *d_light_cdf = nullptr; uint32_t n_lights = 0;
+    uint32_t built_options = 0;                   // scene options the current device scene was built with
     uint32_t bvh_depth = 0;
     bool scene_ready = false;
     bool textures_dirty = true;
@@ -62,7 +67,7 @@ struct ptx_context {
     uint64_t path_capacity = 0;
     uint64_t target_paths = 32u << 20;
     uint32_t extend_waves = 4096;           // persistent grid of the traversal kernel
-    void *d_rays[2] = {nullptr, nullptr};   // two ray queues (three 16-byte planes each), ping-pong per bounce
+    void *d_rays[3] = {nullptr, nullptr, nullptr};   // two ray queues (four 16-byte planes each), ping-pong per bounce; [2]: occlusion rays (lit integrator, allocated on first use)
     HitOut *d_hits = nullptr;
     float4 *d_results = nullptr;
     uint32_t *d_counters = nullptr;
@@ -102,7 +107,7 @@ template <class T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; }
 
 void free_paths(ptx_context *c)
 {
-    dfree(c->d_rays[0]); dfree(c->d_rays[1]); dfree(c->d_hits); dfree(c->d_results);
+    dfree(c->d_rays[0]); dfree(c->d_rays[1]); dfree(c->d_rays[2]); dfree(c->d_hits); dfree(c->d_results);
     c->path_capacity = 0;
 }
 
@@ -116,6 +121,31 @@ int ensure_paths(ptx_context *c, uint64_t n)
     HIP_TRY(c, hipMalloc((void **)&c->d_results, n * sizeof(float4)));
     c->path_capacity = n;
     return PTX_OK;
+}
+
+int ensure_shadow_queue(ptx_context *c)
+{
+    if (c->d_rays[2]) return PTX_OK;
+    HIP_TRY(c, hipMalloc(&c->d_rays[2], c->path_capacity * kRayBytes));
+    return PTX_OK;
+}
+
+// Build extension (PTX_SCENE_WORLD_NORMALS): cofactor matrix of the 3x3 part of the instance transform with
+// the sign of its determinant folded in (= det x inverse transpose); same expression tree as the oracle's.
+void normal_matrix(const float m[3][4], float c[9])
+{
+    const float *r0 = m[0], *r1 = m[1], *r2 = m[2];
+    float c0[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+    float c1[3] = {r2[1] * r0[2] - r2[2] * r0[1], r2[2] * r0[0] - r2[0] * r0[2], r2[0] * r0[1] - r2[1] * r0[0]};
+    float c2[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+    float det = (r0[0] * c0[0] + r0[1] * c0[1]) + r0[2] * c0[2];
+    float sg = det < 0.0f ? -1.0f : 1.0f;
+    for (int k = 0; k < 3; ++k) { c[k] = c0[k] * sg; c[3 + k] = c1[k] * sg; c[6 + k] = c2[k] * sg; }
+}
+
+void normal_to_world(const float c[9], const float n[3], float out[3])
+{
+    for (int r = 0; r < 3; ++r) out[r] = (c[r * 3] * n[0] + c[r * 3 + 1] * n[1]) + c[r * 3 + 2] * n[2];
 }
 
 void srgb_lut(float *lut)
@@ -210,8 +240,8 @@ int ptx_create_with_limits(int device_ordinal, const ptx_limits *limits, ptx_con
     CREATE_TRY(hipSetDevice(device_ordinal));
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_TRY(hipMalloc((void **)&c->d_counters, kNumCounters * sizeof(uint32_t)));
-    CREATE_TRY(hipMalloc((void **)&c->d_totals, 11 * sizeof(uint64_t)));
-    CREATE_TRY(hipMemset(c->d_totals, 0, 11 * sizeof(uint64_t)));
+    CREATE_TRY(hipMalloc((void **)&c->d_totals, kNumTotals * sizeof(uint64_t)));
+    CREATE_TRY(hipMemset(c->d_totals, 0, kNumTotals * sizeof(uint64_t)));
     CREATE_TRY(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
     c->extend_waves = extend_resident_waves(device_ordinal);
     if (const char *ew = getenv("PTX_EXTEND_WAVES")) { long v = strtol(ew, nullptr, 10); if (v > 0) c->extend_waves = (uint32_t)v; }
@@ -233,6 +263,7 @@ int ptx_destroy(ptx_context *c)
     for (EventPair &p : c->event_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (TexDesc &t : c->textures) { void *p = (void *)t.texels; if (p) (void)hipFree(p); }
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_textures); dfree(c->d_lut);
+    dfree(c->d_lit_materials); dfree(c->d_lights); dfree(c->d_light_cdf);
     dfree(c->d_albedo); dfree(c->d_normal); dfree(c->d_depth); dfree(c->d_ids);
     free_paths(c);
     dfree(c->d_counters); dfree(c->d_totals);
@@ -273,6 +304,30 @@ int ptx_add_material(ptx_context *c, const ptx_material *m, uint32_t *index)
         return fail(c, PTX_ERR_CAPACITY, "ptx_add_material: material buffer overflow"); // scene/mod.rs:347-349
     *index = (uint32_t)c->materials.size();
     c->materials.push_back(*m);
+    ptx_material_ext e; memset(&e, 0, sizeof e); e.ior = 1.5f;
+    c->material_ext.push_back(e);
+    return PTX_OK;
+}
+
+int ptx_set_material_ext(ptx_context *c, uint32_t index, const ptx_material_ext *ext)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (!ext) return fail(c, PTX_ERR_INVALID, "ptx_set_material_ext: NULL argument");
+    if (index >= c->materials.size()) return fail(c, PTX_ERR_INVALID, "ptx_set_material_ext: material index out of range");
+    if (!(ext->ior > 0.0f) || !(ext->transmission >= 0.0f && ext->transmission <= 1.0f) ||
+        !(ext->emissive[0] >= 0.0f && ext->emissive[1] >= 0.0f && ext->emissive[2] >= 0.0f))
+        return fail(c, PTX_ERR_INVALID, "ptx_set_material_ext: ior must be > 0, transmission in [0,1], emission >= 0");
+    c->material_ext[index] = *ext;
+    c->material_ext[index]._pad[0] = c->material_ext[index]._pad[1] = c->material_ext[index]._pad[2] = 0;
+    return PTX_OK;
+}
+
+int ptx_set_scene_options(ptx_context *c, uint32_t options)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (options & ~(uint32_t)(PTX_SCENE_WORLD_NORMALS | PTX_SCENE_TEXTURE_TIMES_FACTOR))
+        return fail(c, PTX_ERR_INVALID, "ptx_set_scene_options: unknown option bit");
+    c->scene_options = options;
     return PTX_OK;
 }
 
@@ -280,6 +335,7 @@ int ptx_add_texture(ptx_context *c, const uint8_t *rgba8, uint32_t w, uint32_t h
 {
     if (!c) return PTX_ERR_INVALID;
     if (!rgba8 || !index || w == 0 || h == 0) return fail(c, PTX_ERR_INVALID, "ptx_add_texture: bad argument");
+    if (srgb & ~(PTX_TEXTURE_SRGB | PTX_TEXTURE_REPEAT)) return fail(c, PTX_ERR_INVALID, "ptx_add_texture: unknown flag bit");
     if (c->textures.size() + 1 > c->limits.max_textures)
         return fail(c, PTX_ERR_CAPACITY, "ptx_add_texture: bindless texture pool size exceeded"); // renderer.rs:899-901
     if (int r = bind(c)) return r;
@@ -288,7 +344,8 @@ int ptx_add_texture(ptx_context *c, const uint8_t *rgba8, uint32_t w, uint32_t h
     HIP_TRY(c, hipMalloc(&d, bytes));
     hipError_t e = hipMemcpy(d, rgba8, bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d); return fail(c, PTX_ERR_HIP, std::string("ptx_add_texture: ") + hipGetErrorString(e)); }
-    TexDesc t; t.texels = (const uint8_t *)d; t.width = w; t.height = h; t.srgb = srgb ? 1u : 0u; t._pad = 0;
+    TexDesc t; t.texels = (const uint8_t *)d; t.width = w; t.height = h; t._pad = 0;
+    t.srgb = (uint32_t)srgb & (uint32_t)(PTX_TEXTURE_SRGB | PTX_TEXTURE_REPEAT);
     *index = (uint32_t)c->textures.size();
     c->textures.push_back(t);
     c->textures_dirty = true;
@@ -359,6 +416,55 @@ int ptx_set_instances(ptx_context *c, const ptx_instance *inst, uint32_t n)
     if (!build_bvh8(wv.data(), n_tris, bvh, threads)) return fail(c, PTX_ERR_INVALID, "ptx_set_instances: BVH build failed");
     if (bvh.depth > kMaxBvhDepth) return fail(c, PTX_ERR_CAPACITY, "ptx_set_instances: BVH deeper than the traversal stack");
 
+    const bool world_normals = (c->scene_options & PTX_SCENE_WORLD_NORMALS) != 0;
+    std::vector<float> cof((size_t)n * 9);
+    for (uint32_t i = 0; i < n; ++i) normal_matrix(inst[i].xform, &cof[(size_t)i * 9]);
+
+    // Lit integrator: the light table = every triangle whose material emits, in (instance, primitive)
+    // order, picked with probability proportional to area x luminance (oracle: build_lights).
+    std::vector<LightRec> lights; std::vector<float> light_cdf;
+    {
+        std::vector<float> power, area;
+        double total = 0.0;
+        for (uint64_t t = 0; t < n_tris; ++t) {
+            const ptx_material_ext &e = c->material_ext[inst[tri_inst[t]].off.material_offset];
+            if (!(e.emissive[0] > 0.0f || e.emissive[1] > 0.0f || e.emissive[2] > 0.0f)) continue;
+            const float *a = &wv[t * 9], *b = a + 3, *d = a + 6;
+            float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {d[0] - a[0], d[1] - a[1], d[2] - a[2]};
+            float cr[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            float len = std::sqrt((cr[0] * cr[0] + cr[1] * cr[1]) + cr[2] * cr[2]);
+            float ar = 0.5f * len;
+            if (!(ar > 0.0f) || !std::isfinite(ar)) continue;
+            float lum = (0.2126f * e.emissive[0] + 0.7152f * e.emissive[1]) + 0.0722f * e.emissive[2];
+            float pw = ar * lum;
+            total += (double)pw;
+            LightRec l;
+            memcpy(l.a, a, 12); memcpy(l.b, b, 12); memcpy(l.c, d, 12);
+            float il = 1.0f / len;
+            l.n[0] = cr[0] * il; l.n[1] = cr[1] * il; l.n[2] = cr[2] * il;
+            l.le_r = e.emissive[0]; l.le_g = e.emissive[1]; l.le_b = e.emissive[2];
+            l.pdf_area = 0.0f;
+            lights.push_back(l); power.push_back(pw); area.push_back(ar);
+        }
+        if (!(total > 0.0)) lights.clear();
+        double run = 0.0;
+        light_cdf.resize(lights.size());
+        for (size_t i = 0; i < lights.size(); ++i) {
+            run += (double)power[i];
+            light_cdf[i] = (float)(run / total);
+            lights[i].pdf_area = (float)((double)power[i] / total) / area[i];
+        }
+        if (!lights.empty()) light_cdf.back() = 1.0f;
+    }
+    std::vector<LitMaterial> lit_materials(c->materials.size());
+    for (size_t i = 0; i < c->materials.size(); ++i) {
+        LitMaterial &lm = lit_materials[i];
+        memset(&lm, 0, sizeof lm);
+        memcpy(lm.emissive, c->material_ext[i].emissive, 12);
+        lm.metallic = c->materials[i].metallic;
+        lm.transmission = c->material_ext[i].transmission; lm.ior = c->material_ext[i].ior;
+    }
+
     uint64_t nt = bvh.tri_order.size();
     std::vector<TriRec> tris(nt);
     std::vector<ShadeRec> shade(nt);
@@ -380,12 +486,20 @@ int ptx_set_instances(ptx_context *c, const ptx_instance *inst, uint32_t n)
         const ptx_material &m = c->materials[in.off.material_offset];
         sr.texture = m.has_base_texture ? m.base_texture_indice : 0xFFFFFFFFu;
         sr.roughness = m.roughness; sr.base_r = m.base_color[0]; sr.base_g = m.base_color[1]; sr.base_b = m.base_color[2];
-        memcpy(sr.n0, a.normal, 12); memcpy(sr.n1, b.normal, 12); memcpy(sr.n2, d.normal, 12);   // object space, as the reference
+        sr.material = in.off.material_offset;
+        if (world_normals) {
+            const float *cf = &cof[(size_t)tri_inst[t] * 9];
+            normal_to_world(cf, a.normal, sr.n0); normal_to_world(cf, b.normal, sr.n1); normal_to_world(cf, d.normal, sr.n2);
+        } else {
+            memcpy(sr.n0, a.normal, 12); memcpy(sr.n1, b.normal, 12); memcpy(sr.n2, d.normal, 12);   // object space, as the reference
+        }
         memcpy(sr.uv0, a.uv, 8); memcpy(sr.uv1, b.uv, 8); memcpy(sr.uv2, d.uv, 8);
     }
 
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade);
+    dfree(c->d_lit_materials); dfree(c->d_lights); dfree(c->d_light_cdf);
+    c->n_lights = 0;
     c->scene_ready = false;
     c->n_nodes = (uint32_t)bvh.nodes.size(); c->n_tris = nt; c->bvh_depth = bvh.depth;
     if (c->n_nodes) {
@@ -398,6 +512,18 @@ int ptx_set_instances(ptx_context *c, const ptx_instance *inst, uint32_t n)
         HIP_TRY(c, hipMalloc((void **)&c->d_shade, nt * sizeof(ShadeRec)));
         HIP_TRY(c, hipMemcpy(c->d_shade, shade.data(), nt * sizeof(ShadeRec), hipMemcpyHostToDevice));
     }
+    if (!lit_materials.empty()) {
+        HIP_TRY(c, hipMalloc((void **)&c->d_lit_materials, lit_materials.size() * sizeof(LitMaterial)));
+        HIP_TRY(c, hipMemcpy(c->d_lit_materials, lit_materials.data(), lit_materials.size() * sizeof(LitMaterial), hipMemcpyHostToDevice));
+    }
+    if (!lights.empty()) {
+        HIP_TRY(c, hipMalloc((void **)&c->d_lights, lights.size() * sizeof(LightRec)));
+        HIP_TRY(c, hipMemcpy(c->d_lights, lights.data(), lights.size() * sizeof(LightRec), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMalloc((void **)&c->d_light_cdf, light_cdf.size() * sizeof(float)));
+        HIP_TRY(c, hipMemcpy(c->d_light_cdf, light_cdf.data(), light_cdf.size() * sizeof(float), hipMemcpyHostToDevice));
+        c->n_lights = (uint32_t)lights.size();
+    }
+    c->built_options = c->scene_options;
     if (c->textures_dirty) {
         dfree(c->d_textures);
         if (!c->textures.empty()) {
@@ -442,6 +568,9 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
     ptx_render_params p;
     if (pp) p = *pp; else ptx_default_params(&p);
     if (p.max_depth > kMaxDepthLimit) return fail(c, PTX_ERR_INVALID, "ptx_render: max_depth above 64");
+    if (p.integrator != PTX_INTEGRATOR_REFERENCE && p.integrator != PTX_INTEGRATOR_LIT)
+        return fail(c, PTX_ERR_INVALID, "ptx_render: unknown integrator");
+    const bool lit = p.integrator == PTX_INTEGRATOR_LIT;
     if (n_samples == 0) return PTX_OK;
     if (int r = bind(c)) return r;
 
@@ -450,8 +579,10 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
     chunk = std::min<uint64_t>(chunk, n_samples);
     if (chunk * npix > 0xFFFFFF00ull) chunk = 0xFFFFFF00ull / npix;
     if (int r = ensure_paths(c, chunk * npix)) return r;
+    if (lit) if (int r = ensure_shadow_queue(c)) return r;
 
     SceneDev sc;
+    sc.lit_materials = c->d_lit_materials; sc.lights = c->d_lights; sc.light_cdf = c->d_light_cdf; sc.n_lights = c->n_lights;
     sc.nodes = c->d_nodes; sc.n_nodes = c->n_nodes; sc.tris = c->d_tris; sc.shade = c->d_shade;
     sc.textures = c->d_textures; sc.n_textures = (uint32_t)c->textures.size(); sc.srgb_lut = c->d_lut;
     ImagesDev img; img.albedo = c->d_albedo; img.normal = c->d_normal; img.depth = c->d_depth; img.ids = c->d_ids;
@@ -461,6 +592,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
     f.seed = u->seed; f.rng_offset = p.rng_sample_offset;
     f.max_depth = p.max_depth; f.t_min = p.t_min; f.t_max = p.t_max; f.normal_eps = p.normal_eps;
     f.z_near = u->z_near; f.z_far = u->z_far;
+    f.tex_times_factor = (c->built_options & PTX_SCENE_TEXTURE_TIMES_FACTOR) ? 1u : 0u;
     const uint32_t bounces = std::max(1u, p.max_depth);
 
     EventPair whole{};
@@ -473,20 +605,29 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
         launch_raygen(c->stream, f, n_paths, make_ray_queue(c->d_rays[0], c->path_capacity), c->d_counters);
         for (uint32_t b = 0; b < bounces; ++b) {
             RayQueue rin = make_ray_queue(c->d_rays[b & 1], c->path_capacity), rout = make_ray_queue(c->d_rays[(b & 1) ^ 1], c->path_capacity);
+            RayQueue shadow_q = make_ray_queue(lit ? c->d_rays[2] : c->d_rays[0], c->path_capacity);
+            uint64_t *trav = c->count_traversal ? c->d_totals + 3 : nullptr;
+            EventPair e{}, e2{};
+            if (c->profiling) { e = get_events(c, 0); HIP_TRY(c, hipEventRecord(e.a, c->stream)); }
+            launch_extend(c->stream, sc, f, rin, c->d_counters + b, c->d_counters + kNextBase + b, n_paths, c->extend_waves, c->d_hits, trav);
             if (c->profiling) {
-                EventPair e = get_events(c, 0);
-                HIP_TRY(c, hipEventRecord(e.a, c->stream));
-                launch_extend(c->stream, sc, f, rin, c->d_counters + b, c->d_counters + kNextBase + b, n_paths, c->extend_waves, c->d_hits, c->count_traversal ? c->d_totals + 3 : nullptr);
-                HIP_TRY(c, hipEventRecord(e.b, c->stream));
-                c->events.push_back(e);
-                EventPair e2 = get_events(c, 1);
-                HIP_TRY(c, hipEventRecord(e2.a, c->stream));
+                HIP_TRY(c, hipEventRecord(e.b, c->stream)); c->events.push_back(e);
+                e2 = get_events(c, 1); HIP_TRY(c, hipEventRecord(e2.a, c->stream));
+            }
+            if (!lit) {
                 launch_shade(c->stream, sc, f, img, b, rin, c->d_hits, c->d_counters, n_paths, rout, c->d_results);
-                HIP_TRY(c, hipEventRecord(e2.b, c->stream));
-                c->events.push_back(e2);
             } else {
-                launch_extend(c->stream, sc, f, rin, c->d_counters + b, c->d_counters + kNextBase + b, n_paths, c->extend_waves, c->d_hits, c->count_traversal ? c->d_totals + 3 : nullptr);
-                launch_shade(c->stream, sc, f, img, b, rin, c->d_hits, c->d_counters, n_paths, rout, c->d_results);
+                launch_shade_lit(c->stream, sc, f, img, b, rin, c->d_hits, c->d_counters, n_paths, rout, shadow_q, c->d_results);
+            }
+            if (c->profiling) { HIP_TRY(c, hipEventRecord(e2.b, c->stream)); c->events.push_back(e2); }
+            if (lit && c->n_lights) {
+                // occlusion rays of this bounce: any-hit traversal, then the unoccluded contributions join the radiance
+                EventPair e3{};
+                if (c->profiling) { e3 = get_events(c, 0); HIP_TRY(c, hipEventRecord(e3.a, c->stream)); }
+                launch_extend(c->stream, sc, f, shadow_q, c->d_counters + kShadowCount + b, c->d_counters + kShadowNext + b, n_paths,
+                              c->extend_waves, c->d_hits, nullptr, true);
+                if (c->profiling) { HIP_TRY(c, hipEventRecord(e3.b, c->stream)); c->events.push_back(e3); }
+                launch_shadow_resolve(c->stream, b, shadow_q, c->d_hits, c->d_counters, n_paths, c->d_results);
             }
         }
         launch_resolve(c->stream, f, img, c->d_results, ns);
@@ -586,7 +727,7 @@ int ptx_get_stats(ptx_context *c, ptx_stats *s)
     if (int r = bind(c)) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_events(c);
-    uint64_t t[11];
+    uint64_t t[kNumTotals];
     HIP_TRY(c, hipMemcpy(t, c->d_totals, sizeof t, hipMemcpyDeviceToHost));
     memset(s, 0, sizeof *s);
     s->rays = t[0]; s->hits = t[1]; s->samples = t[2]; s->nodes_fetched = t[3]; s->tris_tested = t[4];
@@ -595,6 +736,7 @@ int ptx_get_stats(ptx_context *c, ptx_stats *s)
     s->bvh_nodes = c->n_nodes; s->bvh_triangles = c->n_tris;
     s->bvh_bytes = (uint64_t)c->n_nodes * sizeof(Bvh8Node) + c->n_tris * (sizeof(TriRec) + sizeof(ShadeRec));
     s->bvh_depth = c->bvh_depth;
+    s->shadow_rays = t[11]; s->lights = c->n_lights;
     return PTX_OK;
 }
 
@@ -604,7 +746,7 @@ int ptx_reset_stats(ptx_context *c)
     if (int r = bind(c)) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_events(c);
-    HIP_TRY(c, hipMemset(c->d_totals, 0, 11 * sizeof(uint64_t)));
+    HIP_TRY(c, hipMemset(c->d_totals, 0, kNumTotals * sizeof(uint64_t)));
     c->extend_ms = c->shade_ms = c->total_ms = 0; c->extend_launches = 0;
     return PTX_OK;
 }

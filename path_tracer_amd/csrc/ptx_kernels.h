@@ -48,13 +48,27 @@ struct alignas(128) ShadeRec {
     float uv0[2], uv1[2], uv2[2];
     float base_g, base_b;
     uint32_t instance, prim;
-    uint32_t _pad;
+    uint32_t material;                  // row of SceneDev::lit_materials (lit integrator only)
 };
 static_assert(sizeof(ShadeRec) == 128, "ShadeRec must be 128 bytes");
 
+// Lit integrator (build extension): per-material inputs beyond the ShadeRec, and the light table.
+struct alignas(16) LitMaterial {
+    float emissive[3]; float metallic;
+    float transmission, ior; uint32_t _pad[2];
+};
+static_assert(sizeof(LitMaterial) == 32, "LitMaterial must be 32 bytes");
+struct alignas(16) LightRec {          // one emissive triangle, world space
+    float a[3]; float pdf_area;        // pick probability / area
+    float b[3]; float le_r;
+    float c[3]; float le_g;
+    float n[3]; float le_b;
+};
+static_assert(sizeof(LightRec) == 64, "LightRec must be 64 bytes");
+
 struct TexDesc {
     const uint8_t *texels;   // RGBA8, row 0 first
-    uint32_t width, height, srgb, _pad;
+    uint32_t width, height, srgb /* bit0 sRGB, bit1 wrap = repeat */, _pad;
 };
 static_assert(sizeof(TexDesc) == 24, "TexDesc must be 24 bytes");
 constexpr uint32_t kLdsTextures = 64;   // descriptors of the first textures are staged in LDS by the shading stage
@@ -65,6 +79,9 @@ struct SceneDev {
     const ShadeRec *shade;
     const TexDesc *textures; uint32_t n_textures;
     const float *srgb_lut;   // 256 floats
+    // lit integrator
+    const LitMaterial *lit_materials;
+    const LightRec *lights; const float *light_cdf; uint32_t n_lights;
 };
 
 struct FrameDev {
@@ -76,6 +93,7 @@ struct FrameDev {
     uint32_t ids_sample;       // sample (within the chunk) whose first hit goes to the id image; 0xFFFFFFFF: none
     uint32_t max_depth;
     float t_min, t_max, normal_eps, z_near, z_far;
+    uint32_t tex_times_factor; // PTX_SCENE_TEXTURE_TIMES_FACTOR
 };
 
 struct ImagesDev {
@@ -86,7 +104,9 @@ struct ImagesDev {
 constexpr uint32_t kMaxDepthLimit = 64;
 constexpr uint32_t kHitCounter = kMaxDepthLimit + 1;
 constexpr uint32_t kNextBase = kMaxDepthLimit + 2;      // counters[kNextBase + b]: fetch cursor of bounce b's extend
-constexpr uint32_t kNumCounters = 2 * kMaxDepthLimit + 3;
+constexpr uint32_t kShadowCount = 2 * kMaxDepthLimit + 3; // counters[kShadowCount + b]: occlusion rays queued by bounce b (lit integrator)
+constexpr uint32_t kShadowNext = 3 * kMaxDepthLimit + 4;  // their fetch cursor
+constexpr uint32_t kNumCounters = 4 * kMaxDepthLimit + 5;
 
 // traversal stack: entries held in LDS per lane, remainder in private memory
 #ifndef PTX_LDS_STACK
@@ -100,14 +120,23 @@ void launch_raygen(hipStream_t s, const FrameDev &f, uint32_t n_paths, RayQueue 
 // `next`: the bounce's fetch cursor (zeroed by raygen); `max_waves`: resident-wave budget of the persistent grid
 void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, RayQueue rays, const uint32_t *count,
                    uint32_t *next, uint32_t capacity, uint32_t max_waves, HitOut *hits,
-                   uint64_t *trav_totals /* NULL: uninstrumented */);
+                   uint64_t *trav_totals /* NULL: uninstrumented */, bool any_hit = false);
 uint32_t extend_resident_waves(int device);
 void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
                   RayQueue rays_in, const HitOut *hits, uint32_t *counters, uint32_t capacity, RayQueue rays_out,
                   float4 *results);
+// Lit integrator: shading with next-event estimation.  Survivors go to rays_out, occlusion rays to
+// `shadow` (count in counters[kShadowCount + depth]); radiance is accumulated in results[path].
+void launch_shade_lit(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
+                      RayQueue rays_in, const HitOut *hits, uint32_t *counters, uint32_t capacity, RayQueue rays_out,
+                      RayQueue shadow, float4 *results);
+// adds the contribution of every unoccluded occlusion ray of bounce `depth` to its path's radiance
+void launch_shadow_resolve(hipStream_t s, uint32_t depth, RayQueue shadow, const HitOut *hits, const uint32_t *counters,
+                           uint32_t capacity, float4 *results);
 void launch_resolve(hipStream_t s, const FrameDev &f, const ImagesDev &img, const float4 *results, uint32_t n_samples);
 void launch_accumulate_stats(hipStream_t s, const uint32_t *counters, uint32_t max_depth, uint64_t n_samples,
                              uint64_t *totals);
+constexpr int kNumTotals = 12;   // rays, hits, samples, nodes, tris, 6 x wave_sched, shadow rays
 void launch_scale_copy(hipStream_t s, const float4 *src, float4 *dst, uint64_t n, float scale);
 
 }  // namespace ptx

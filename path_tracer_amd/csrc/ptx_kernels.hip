@@ -154,7 +154,9 @@ __device__ __forceinline__ uint32_t lane_read_u(uint32_t v, uint32_t src_lane)
     return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
 }
 
-template <bool kStats>
+//  * kAnyHit (occlusion rays of the lit integrator): the first accepted triangle ends the ray's walk;
+//    hits[ray].tri != miss then only means "occluded".
+template <bool kStats, bool kAnyHit>
 __global__ void __launch_bounds__(kExtendBlock) __attribute__((amdgpu_waves_per_eu(PTX_EXTEND_WAVES_PER_EU, PTX_EXTEND_WAVES_PER_EU)))
 k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *__restrict__ count,
            uint32_t *__restrict__ next, HitOut *__restrict__ hits, unsigned long long *__restrict__ trav_totals,
@@ -309,7 +311,10 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                                 uint32_t ia = wa[3], pa = wa[7], ib = wb[3], pb = wb[7];
                                 better = ia < ib || (ia == ib && pa < pb);
                             }
-                            if (better) { tr.hit.t = rt; tr.hit.tri = rti; }
+                            if (better) {
+                                tr.hit.t = rt; tr.hit.tri = rti;
+                                if (kAnyHit) { next_ni = 0xFFFFFFFFu; st.sp = 0; tr.ng_mask = 0; }
+                            }
                         }
                         cand = cand && !won;
                     }
@@ -337,6 +342,7 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
 __device__ __forceinline__ f3 sample_texture(const TexDesc &tx, const float *lut, float u, float v)
 {
     // vulkano SamplerCreateInfo::default(): nearest, clamp-to-edge, LOD 0 (graphics.rs:453-459)
+    if (tx.srgb & 2u) { u = u - floorf(u); v = v - floorf(v); }   // build extension: wrap = repeat
     float fu = floorf(u * (float)tx.width), fv = floorf(v * (float)tx.height);
     float mu = (float)(tx.width - 1u), mv = (float)(tx.height - 1u);
     if (!(fu >= 0.0f)) fu = 0.0f;
@@ -345,7 +351,7 @@ __device__ __forceinline__ f3 sample_texture(const TexDesc &tx, const float *lut
     if (fv > mv) fv = mv;
     uint32_t texel = *reinterpret_cast<const uint32_t *>(tx.texels + ((uint64_t)(uint32_t)fv * tx.width + (uint32_t)fu) * 4u);
     uint32_t r = texel & 0xFFu, g = (texel >> 8) & 0xFFu, b = (texel >> 16) & 0xFFu;
-    if (tx.srgb) return mk3(lut[r], lut[g], lut[b]);
+    if (tx.srgb & 1u) return mk3(lut[r], lut[g], lut[b]);
     return mk3((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f);
 }
 
@@ -425,6 +431,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
             if (tex != 0xFFFFFFFFu) {
                 if (tex < kLdsTextures) albedo = sample_texture(s_tex[tex], s_lut, tu, tv);
                 else albedo = sample_texture(sc.textures[tex], s_lut, tu, tv);
+                if (f.tex_times_factor) albedo = albedo * mk3(t2.w, s3.w, s4.x);   // build extension; the reference drops the factor
             } else {
                 albedo = mk3(t2.w, s3.w, s4.x);
             }
@@ -507,6 +514,294 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
     }
 }
 
+// ---------------------------------------------------------------- shade, lit integrator
+// Build extension: the stage that replaces k_shade when params.integrator is
+// PTX_INTEGRATOR_LIT.  Specification: oracle/pt_oracle.c raygen_pixel_lit -- same expression trees, so
+// the image is bit-identical to the oracle's.  Per hit: emission (camera / specular paths), one
+// next-event-estimation sample (light picked by binary search of the power CDF, occlusion ray queued
+// for an any-hit traversal), BSDF sampling (Lambert + GGX or smooth dielectric), Russian roulette.
+// Two block-level compactions: surviving rays and occlusion rays, one queue-tail atomic each.
+struct BlockScan {
+    uint32_t *wave_cnt;   // kShadeBlock / 64 words of LDS
+    uint32_t *base;       // one word of LDS
+};
+__device__ __forceinline__ uint32_t block_reserve(bool flag, const BlockScan &bs, uint32_t *counter)
+{
+    const unsigned long long m = __ballot(flag);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) bs.wave_cnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        uint32_t c = lane < kShadeBlock / 64 ? bs.wave_cnt[lane] : 0u;
+#pragma unroll
+        for (int d = 1; d < kShadeBlock / 64; d <<= 1) {
+            uint32_t t = __shfl_up(c, d, 64);
+            if ((int)lane >= d) c += t;
+        }
+        if (lane < kShadeBlock / 64) bs.wave_cnt[lane] = c;
+        if (lane == kShadeBlock / 64 - 1) *bs.base = c ? atomicAdd(counter, c) : 0u;
+    }
+    __syncthreads();
+    const uint32_t before = wave ? bs.wave_cnt[wave - 1] : 0u;
+    const uint32_t slot = *bs.base + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    __syncthreads();      // the LDS words are reused by the next reservation
+    return slot;
+}
+
+__global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev f, ImagesDev img, uint32_t depth,
+                                                            RayQueue rays_in, const HitOut *__restrict__ hits,
+                                                            uint32_t *__restrict__ counters, uint32_t capacity,
+                                                            RayQueue rays_out, RayQueue shadow, float4 *__restrict__ results)
+{
+    __shared__ float s_lut[256];
+    __shared__ TexDesc s_tex[kLdsTextures];
+    __shared__ uint32_t s_cnt[kShadeBlock / 64];
+    __shared__ uint32_t s_base, s_hits;
+
+    const uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x;
+    if (blockIdx.x * kShadeBlock >= counters[depth]) return;
+    if (threadIdx.x == 0) s_hits = 0;
+    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
+    float2 hr = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
+    if (i < capacity) {
+        r0 = rays_in.org[i]; r1 = rays_in.dir[i]; r2 = rays_in.thr[i];
+        hr = *reinterpret_cast<const float2 *>(hits + i);
+    }
+    const uint32_t n_live = counters[depth];
+    if (threadIdx.x < 256) s_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];
+    {
+        const uint32_t nw = (sc.n_textures < kLdsTextures ? sc.n_textures : kLdsTextures) * (uint32_t)(sizeof(TexDesc) / 4);
+        for (uint32_t w = threadIdx.x; w < nw; w += kShadeBlock)
+            reinterpret_cast<uint32_t *>(s_tex)[w] = reinterpret_cast<const uint32_t *>(sc.textures)[w];
+    }
+    const bool valid = i < capacity && i < n_live;
+    const uint32_t tri = valid ? __float_as_uint(hr.y) : 0xFFFFFFFFu;
+    float4 t0 = r0, t1 = r0, t2 = r0, s0 = r0, s1 = r0, s2 = r0, s3 = r0, s4 = r0;
+    if (tri != 0xFFFFFFFFu) {
+        const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri);
+        t0 = sp[0]; t1 = sp[1]; t2 = sp[2]; s0 = sp[3]; s1 = sp[4]; s2 = sp[5]; s3 = sp[6]; s4 = sp[7];
+    }
+    __syncthreads();
+
+    bool alive = false, was_hit = false, want_shadow = false;
+    float4 o0, o1, o2, o3, q0, q1, q2, q3;
+    if (valid) {
+        const f3 o = mk3(r0.x, r0.y, r0.z), dir = mk3(r1.x, r1.y, r1.z);
+        const uint32_t path = __float_as_uint(r0.w), uv_state = __float_as_uint(r1.w);
+        const uint32_t sample = path / f.n_pixels, pix = path - sample * f.n_pixels;
+        const uint32_t acc = f.mean_base + sample;
+        const uint32_t rng_acc = acc + f.rng_offset;
+        const bool spec = (__float_as_uint(r2.w) & 1u) == 0u;      // bit0 set: the previous bounce was diffuse / glossy
+        f3 thr = mk3(r2.x, r2.y, r2.z);
+        f3 add = mk3(0.0f, 0.0f, 0.0f);
+        bool have_add = false;
+        f3 gb_normal = mk3(0.0f, 0.0f, 0.0f);
+        float gb_dist = 3.402823466e+38f;
+        bool done = false, next_spec = true;
+        f3 new_o = o, new_d = dir;
+        uint32_t id_inst = 0xFFFFFFFFu, id_prim = 0xFFFFFFFFu;
+        if (tri == 0xFFFFFFFFu) {
+            add = thr * sky_color(dir);
+            have_add = true;
+            done = true;
+        } else {
+            was_hit = true;
+            const f3 va = mk3(t0.x, t0.y, t0.z), vb = mk3(t1.x, t1.y, t1.z), vc = mk3(t2.x, t2.y, t2.z);
+            float hu, hv;
+            tri_uv(o, dir, va, vb, vc, hu, hv);
+            const float bx = 1.0f - hu - hv, by = hu, bz = hv;
+            const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
+            f3 ns = normalize((n0 * bx + n1 * by) + n2 * bz);
+            f3 ng = normalize(cross(vb - va, vc - va));
+            bool front = true;
+            if (dot(ng, dir) > 0.0f) { ng = ng * -1.0f; front = false; }
+            if (dot(ns, ng) < 0.0f) ns = ns * -1.0f;
+            const float tu = (s2.y * bx + s2.w * by) + s3.y * bz;
+            const float tv = (s2.z * bx + s3.x * by) + s3.z * bz;
+            const f3 P = o + dir * hr.x;
+            const LitMaterial lm = sc.lit_materials[__float_as_uint(s4.w)];
+            f3 albedo = mk3(t2.w, s3.w, s4.x);
+            const uint32_t tex = __float_as_uint(t0.w);
+            if (tex != 0xFFFFFFFFu) {
+                f3 tx = tex < kLdsTextures ? sample_texture(s_tex[tex], s_lut, tu, tv) : sample_texture(sc.textures[tex], s_lut, tu, tv);
+                albedo = tx * albedo;
+            }
+            const f3 wo = dir * -1.0f;
+            const f3 up_o = P + ng * f.normal_eps;
+            gb_normal = ns;
+            gb_dist = length(up_o - o);
+            if (depth == 0 && sample == f.ids_sample) { id_inst = __float_as_uint(s4.y); id_prim = __float_as_uint(s4.z); }
+
+            if (spec && (lm.emissive[0] > 0.0f || lm.emissive[1] > 0.0f || lm.emissive[2] > 0.0f)) {
+                add = thr * mk3(lm.emissive[0], lm.emissive[1], lm.emissive[2]);
+                have_add = true;
+            }
+            const float u_lobe = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedLobe);
+            const float u1 = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedU1);
+            const float u2 = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedU2);
+            if (lm.transmission > 0.0f && u_lobe < lm.transmission) {
+                // smooth dielectric
+                const float ior = lm.ior;
+                const float eta = front ? 1.0f / ior : ior;
+                float cosi = dot(wo, ns);
+                if (cosi < 0.0f) cosi = 0.0f;
+                if (cosi > 1.0f) cosi = 1.0f;
+                const float sin2t = (eta * eta) * (1.0f - cosi * cosi);
+                bool reflect = true;
+                float cost = 0.0f;
+                if (sin2t < 1.0f) {
+                    cost = sqrtf(1.0f - sin2t);
+                    float r0s = (1.0f - ior) / (1.0f + ior);
+                    r0s = r0s * r0s;
+                    const float c = front ? cosi : cost;
+                    const float fr = r0s + (1.0f - r0s) * pow5(1.0f - c);
+                    reflect = u1 < fr;
+                }
+                if (reflect) {
+                    new_d = normalize(dir + ns * (2.0f * cosi));
+                    new_o = up_o;
+                } else {
+                    new_d = normalize(dir * eta + ns * (eta * cosi - cost));
+                    new_o = P - ng * f.normal_eps;
+                    thr = thr * albedo;
+                }
+                next_spec = true;
+            } else {
+                const float rough = t1.w, metal = lm.metallic;
+                float alpha = rough * rough;
+                if (alpha < 0.0025f) alpha = 0.0025f;
+                const float a2 = alpha * alpha;
+                const float om = 1.0f - metal;
+                const f3 f0 = mk3(0.04f * om + albedo.x * metal, 0.04f * om + albedo.y * metal, 0.04f * om + albedo.z * metal);
+                const f3 diff = albedo * om;
+                const float p_spec = 0.25f + 0.75f * metal;
+
+                // next-event estimation
+                if (sc.n_lights) {
+                    const float ul = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedLight);
+                    uint32_t lo = 0, hi = sc.n_lights;
+                    while (lo < hi) { uint32_t mid = (lo + hi) / 2u; if (sc.light_cdf[mid] <= ul) lo = mid + 1u; else hi = mid; }
+                    if (lo >= sc.n_lights) lo = sc.n_lights - 1u;
+                    const float4 *lp = reinterpret_cast<const float4 *>(sc.lights + lo);
+                    const float4 l0 = lp[0], l1 = lp[1], l2 = lp[2], l3 = lp[3];
+                    const float a = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedLu);
+                    const float b = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedLv);
+                    const float su = sqrtf(a);
+                    const float w0 = 1.0f - su, w1 = su * (1.0f - b), w2 = su * b;
+                    const f3 pl = (mk3(l0.x, l0.y, l0.z) * w0 + mk3(l1.x, l1.y, l1.z) * w1) + mk3(l2.x, l2.y, l2.z) * w2;
+                    const f3 dl = pl - up_o;
+                    const float dist2 = dot(dl, dl);
+                    const float inv_dist = 1.0f / sqrtf(dist2);
+                    const f3 wl = dl * inv_dist;
+                    const float cos_g = dot(ng, wl);
+                    const float cos_l = fabsf(dot(mk3(l3.x, l3.y, l3.z), wl));
+                    f3 fb; float pdf_unused;
+                    if (dist2 > 0.0f && cos_g > 0.0f && cos_l > 0.0f && bsdf_eval(ns, wo, wl, diff, f0, a2, p_spec, fb, pdf_unused)) {
+                        const float cos_s = dot(ns, wl);
+                        const float gterm = (cos_s * cos_l) / (dist2 * l0.w);
+                        const f3 c = ((thr * fb) * mk3(l1.w, l2.w, l3.w)) * gterm;
+                        want_shadow = true;
+                        q0 = make_float4(up_o.x, up_o.y, up_o.z, r0.w);
+                        q1 = make_float4(dl.x, dl.y, dl.z, 0.0f);
+                        q2 = make_float4(c.x, c.y, c.z, 0.0f);
+                        float ix, iy, iz;
+                        uint32_t oct = ray_slab_setup(up_o, dl, ix, iy, iz);
+                        q3 = make_float4(ix, iy, iz, __uint_as_float(oct));
+                    }
+                }
+
+                // sample the next direction
+                const float u_mix = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedMix);
+                f3 wi;
+                if (u_mix < p_spec) {
+                    const f3 hv3 = ggx_sample_vndf(ns, wo, alpha, u1, u2);
+                    wi = normalize(hv3 * (2.0f * dot(wo, hv3)) - wo);
+                } else {
+                    const float r = sqrtf(u1), phi = 6.283185307f * u2;
+                    float sn, cs;
+                    sincos_2pi(phi, sn, cs);
+                    const float lx = r * cs, ly = r * sn, oz = 1.0f - u1;
+                    const float lz = sqrtf(0.0f < oz ? oz : 0.0f);
+                    f3 tt, bb;
+                    create_basis(ns, tt, bb);
+                    wi = normalize((tt * lx + bb * ly) + ns * lz);
+                }
+                f3 fb; float pdf;
+                if (dot(wi, ng) > 0.0f && bsdf_eval(ns, wo, wi, diff, f0, a2, p_spec, fb, pdf) && pdf > 0.0f) {
+                    const float wgt = dot(ns, wi) / pdf;
+                    thr = thr * (fb * wgt);
+                    new_d = wi;
+                    new_o = up_o;
+                } else {
+                    done = true;
+                }
+                next_spec = false;
+            }
+            // Russian roulette
+            if (!done && depth >= 3u) {
+                float pr = fmaxf(thr.x, fmaxf(thr.y, thr.z));
+                if (pr > 1.0f) pr = 1.0f;
+                if (pr < 0.05f) pr = 0.05f;
+                if (rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedRr) >= pr) done = true;
+                else thr = thr * (1.0f / pr);
+            }
+            if (!done && !(finite3(thr) && finite3(new_d))) done = true;
+        }
+
+        // radiance so far: results[path] is this path's L, started at bounce 0
+        if (depth == 0 || have_add) {
+            float4 cur = depth == 0 ? make_float4(0.0f, 0.0f, 0.0f, 1.0f) : results[path];
+            if (have_add) { cur.x = cur.x + add.x; cur.y = cur.y + add.y; cur.z = cur.z + add.z; }
+            cur.w = 1.0f;
+            results[path] = cur;
+        }
+        if (depth == 0) {
+            if (sample == f.ids_sample) img.ids[pix] = make_uint2(id_inst, id_prim);
+            if (acc == 0) {
+                float z_range = f.z_far - f.z_near;
+                float zn = (gb_dist - f.z_near) / z_range;
+                zn = fminf(fmaxf(zn, 0.0f), 1.0f);
+                img.depth[pix] = zn;
+                img.normal[pix] = make_float4(gb_normal.x, gb_normal.y, gb_normal.z, 1.0f);
+            }
+        }
+        if (!done && depth + 1u < f.max_depth) {
+            alive = true;
+            o0 = make_float4(new_o.x, new_o.y, new_o.z, r0.w);
+            o1 = make_float4(new_d.x, new_d.y, new_d.z, r1.w);
+            o2 = make_float4(thr.x, thr.y, thr.z, __uint_as_float(next_spec ? 0u : 1u));
+            float ix, iy, iz;
+            uint32_t oct = ray_slab_setup(new_o, new_d, ix, iy, iz);
+            o3 = make_float4(ix, iy, iz, __uint_as_float(oct));
+        }
+    }
+
+    BlockScan bs; bs.wave_cnt = s_cnt; bs.base = &s_base;
+    {
+        // hits of the block: LDS atomic per wave, one global atomic per block (a single word takes ~88 M atomics/s)
+        unsigned long long hitm = __ballot(was_hit);
+        if ((threadIdx.x & 63u) == 0 && hitm) atomicAdd(&s_hits, (uint32_t)__popcll(hitm));
+    }
+    const uint32_t slot = block_reserve(alive, bs, &counters[depth + 1u]);
+    if (threadIdx.x == 0 && s_hits) atomicAdd(&counters[kHitCounter], s_hits);
+    if (alive) { rays_out.org[slot] = o0; rays_out.dir[slot] = o1; rays_out.thr[slot] = o2; rays_out.inv[slot] = o3; }
+    const uint32_t sslot = block_reserve(want_shadow, bs, &counters[kShadowCount + depth]);
+    if (want_shadow) { shadow.org[sslot] = q0; shadow.dir[sslot] = q1; shadow.thr[sslot] = q2; shadow.inv[sslot] = q3; }
+}
+
+__global__ void __launch_bounds__(256) k_shadow_resolve(uint32_t depth, RayQueue shadow, const HitOut *__restrict__ hits,
+                                                        const uint32_t *__restrict__ counters, float4 *__restrict__ results)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= counters[kShadowCount + depth]) return;
+    if (hits[i].tri != 0xFFFFFFFFu) return;        // occluded
+    const uint32_t path = __float_as_uint(shadow.org[i].w);
+    const float4 c = shadow.thr[i];
+    float4 cur = results[path];
+    cur.x = cur.x + c.x; cur.y = cur.y + c.y; cur.z = cur.z + c.z;
+    results[path] = cur;
+}
+
 // ---------------------------------------------------------------- resolve
 __global__ void __launch_bounds__(256) k_resolve(FrameDev f, ImagesDev img, const float4 *__restrict__ results,
                                                  uint32_t n_samples)
@@ -530,9 +825,10 @@ __global__ void k_accumulate_stats(const uint32_t *__restrict__ counters, uint32
                                    uint64_t *__restrict__ totals)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        uint64_t rays = 0;
-        for (uint32_t b = 0; b < max_depth; ++b) rays += counters[b];
+        uint64_t rays = 0, shadow = 0;
+        for (uint32_t b = 0; b < max_depth; ++b) { rays += counters[b]; shadow += counters[kShadowCount + b]; }
         totals[0] += rays;
+        totals[11] += shadow;
         totals[1] += counters[kHitCounter];
         totals[2] += n_samples;
     }
@@ -566,20 +862,21 @@ static const ExtendSched &extend_sched()
 }
 
 void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, RayQueue rays, const uint32_t *count,
-                   uint32_t *next, uint32_t capacity, uint32_t max_waves, HitOut *hits, uint64_t *trav_totals)
+                   uint32_t *next, uint32_t capacity, uint32_t max_waves, HitOut *hits, uint64_t *trav_totals, bool any_hit)
 {
     const ExtendSched &sched = extend_sched();
     uint32_t blocks = std::min((capacity + kExtendBlock - 1u) / kExtendBlock, max_waves);
     if (!blocks) return;
     unsigned long long *tt = reinterpret_cast<unsigned long long *>(trav_totals);
-    if (tt) hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, next, hits, tt, sched);
-    else hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, next, hits, tt, sched);
+    if (any_hit) hipLaunchKernelGGL((k_extend<false, true>), dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, kLitShadowTmax, rays, count, next, hits, (unsigned long long *)nullptr, sched);
+    else if (tt) hipLaunchKernelGGL((k_extend<true, false>), dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, next, hits, tt, sched);
+    else hipLaunchKernelGGL((k_extend<false, false>), dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, next, hits, tt, sched);
 }
 
 uint32_t extend_resident_waves(int device)
 {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend<false>, kExtendBlock, 0) != hipSuccess || per_cu <= 0) per_cu = 24;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend<false, false>, kExtendBlock, 0) != hipSuccess || per_cu <= 0) per_cu = 24;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
     return (uint32_t)per_cu * (uint32_t)cus;
 }
@@ -592,6 +889,24 @@ void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const Im
     if (!blocks) return;
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kShadeBlock), 0, s, sc, f, img, depth, rays_in, hits, counters,
                        capacity, rays_out, results);
+}
+
+void launch_shade_lit(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
+                      RayQueue rays_in, const HitOut *hits, uint32_t *counters, uint32_t capacity, RayQueue rays_out,
+                      RayQueue shadow, float4 *results)
+{
+    uint32_t blocks = (capacity + kShadeBlock - 1u) / kShadeBlock;
+    if (!blocks) return;
+    hipLaunchKernelGGL(k_shade_lit, dim3(blocks), dim3(kShadeBlock), 0, s, sc, f, img, depth, rays_in, hits, counters,
+                       capacity, rays_out, shadow, results);
+}
+
+void launch_shadow_resolve(hipStream_t s, uint32_t depth, RayQueue shadow, const HitOut *hits, const uint32_t *counters,
+                           uint32_t capacity, float4 *results)
+{
+    uint32_t blocks = (capacity + 255u) / 256u;
+    if (!blocks) return;
+    hipLaunchKernelGGL(k_shadow_resolve, dim3(blocks), dim3(256), 0, s, depth, shadow, hits, counters, results);
 }
 
 void launch_resolve(hipStream_t s, const FrameDev &f, const ImagesDev &img, const float4 *results, uint32_t n_samples)

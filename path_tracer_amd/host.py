@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpt_host.so")
 EXPORTS = ["pth_last_error", "pth_renderer_create", "pth_renderer_destroy", "pth_renderer_context", "pth_import_gltf",
            "pth_set_camera", "pth_set_seed", "pth_set_params", "pth_set_accumulation_limit", "pth_accumulated_count",
            "pth_resize", "pth_record_commands", "pth_record_commands_batch", "pth_save_image", "pth_scene_counts",
-           "pth_scene_copy", "pth_camera_matrices", "pth_decode_image", "pth_encode_png_rgb8"]
+           "pth_scene_copy", "pth_camera_matrices", "pth_decode_image", "pth_encode_png_rgb8", "pth_set_ref_quirks"]
 _lib = None
 
 
@@ -37,6 +37,7 @@ def load():
     L.pth_renderer_context.argtypes = [vp]
     L.pth_renderer_context.restype = vp
     L.pth_import_gltf.argtypes = [vp, C.c_char_p, C.c_float, C.c_float, C.c_float]
+    L.pth_set_ref_quirks.argtypes = [vp, C.c_int]
     L.pth_set_camera.argtypes = [vp, fp, fp, C.c_float, C.c_float, C.c_float]
     L.pth_set_seed.argtypes = [vp, C.c_uint32, C.c_int]
     L.pth_set_params.argtypes = [vp, C.POINTER(capi.RenderParams)]
@@ -125,6 +126,11 @@ class Renderer:
 
     def import_gltf(self, path, position_offset=(0.0, 0.0, 0.0)):
         _check(self._L.pth_import_gltf(self.handle, path.encode(), *[float(x) for x in position_offset]))
+
+    def set_ref_quirks(self, on):
+        """False = SURVEY 8f.2's --no-ref-quirks: world-space normals, texel x baseColorFactor, child nodes,
+        sampler wrap modes.  Call before import_gltf."""
+        _check(self._L.pth_set_ref_quirks(self.handle, int(bool(on))))
 
     def set_camera(self, pos, quat=(0, 0, 0, 1), fov_y=np.deg2rad(np.float32(70.0)), z_near=0.1, z_far=1000.0):
         _check(self._L.pth_set_camera(self.handle, _fp(np.asarray(pos, np.float32)), _fp(np.asarray(quat, np.float32)),

@@ -36,6 +36,8 @@ int pth_import_gltf(void *r, const char *path, float ox, float oy, float oz)
     return guard([&] { Scene::import_gltf(*(Renderer *)r, path, Vec3(ox, oy, oz)); });
 }
 
+int pth_set_ref_quirks(void *r, int on) { return guard([&] { ((Renderer *)r)->set_ref_quirks(on != 0); }); }
+
 int pth_set_camera(void *r, const float pos[3], const float quat_xyzw[4], float fov_y, float z_near, float z_far)
 {
     Renderer *R = (Renderer *)r;

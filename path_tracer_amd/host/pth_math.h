@@ -30,6 +30,12 @@ struct Quat {
     }
     // glam Quat::from_rotation_y
     static Quat from_rotation_y(float angle) { float h = angle * 0.5f; return {0.0f, std::sin(h), 0.0f, std::cos(h)}; }
+    // glam Quat::mul_quat (Hamilton product, this * o)
+    Quat mul(Quat o) const
+    {
+        return {w * o.x + x * o.w + y * o.z - z * o.y, w * o.y - x * o.z + y * o.w + z * o.x,
+                w * o.z + x * o.y - y * o.x + z * o.w, w * o.w - x * o.x - y * o.y - z * o.z};
+    }
     // glam Quat::mul_vec3
     Vec3 mul_vec3(Vec3 v) const
     {

@@ -51,11 +51,20 @@ const Texture *Renderer::lookup_texture(const std::string &ident) const
     return it == loaded_textures_map_.end() ? nullptr : &it->second;
 }
 
-uint32_t Renderer::add_texture(const uint8_t *rgba8, uint32_t w, uint32_t h, bool srgb)
+uint32_t Renderer::add_texture(const uint8_t *rgba8, uint32_t w, uint32_t h, bool srgb, bool repeat)
 {
     uint32_t idx = 0;
-    if (ptx_add_texture(ctx_, rgba8, w, h, srgb ? 1 : 0, &idx)) ptx_throw(ctx_, "Bindless texture pool size exceeded");
+    int flags = (srgb ? PTX_TEXTURE_SRGB : 0) | (repeat ? PTX_TEXTURE_REPEAT : 0);
+    if (ptx_add_texture(ctx_, rgba8, w, h, flags, &idx)) ptx_throw(ctx_, "Bindless texture pool size exceeded");
     return idx;
+}
+
+void Renderer::set_ref_quirks(bool on)
+{
+    ref_quirks_ = on;
+    if (ptx_set_scene_options(ctx_, on ? 0u : (uint32_t)(PTX_SCENE_WORLD_NORMALS | PTX_SCENE_TEXTURE_TIMES_FACTOR)))
+        ptx_throw(ctx_, "set_ref_quirks");
+    scene.world_mut();      // the device scene has to be rebuilt with the new options
 }
 
 void Renderer::sync_instances()

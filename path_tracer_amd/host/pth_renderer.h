@@ -31,7 +31,13 @@ public:
     // renderer.rs:867-904
     const Texture *lookup_texture(const std::string &ident) const;
     void add_texture_to_lookup_map(const std::string &ident, const Texture &t) { loaded_textures_map_[ident] = t; }
-    uint32_t add_texture(const uint8_t *rgba8, uint32_t w, uint32_t h, bool srgb);
+    uint32_t add_texture(const uint8_t *rgba8, uint32_t w, uint32_t h, bool srgb, bool repeat = false);
+
+    // Build extension (the --no-ref-quirks switch; default true = the reference's behaviour).
+    // false: normals go to world space, texels are multiplied by baseColorFactor, import_gltf descends into
+    // child nodes and honours the glTF sampler's wrap mode.  Call before importing / the first frame.
+    void set_ref_quirks(bool on);
+    bool ref_quirks() const { return ref_quirks_; }
 
     // renderer.rs:906-1083: one frame = one sample per pixel.  The reference draws a fresh
     // rand::random() seed per frame (renderer.rs:1005,1021); set fixed_seed for reproducible
@@ -72,6 +78,7 @@ private:
     std::map<std::string, Texture> loaded_textures_map_;
     uint64_t rng_state_ = 0;
     bool rng_started_ = false;
+    bool ref_quirks_ = true;
 };
 
 }  // namespace pth

@@ -111,6 +111,19 @@ Material material_from_gltf(const Json &doc, const Json *gltf_mat, Renderer &ren
             if (!image.has("uri")) throw std::runtime_error("glTF: buffer-view images are not supported");
             std::string uri = image.get_string("uri", "");
             std::string ident = "gltf_" + uri;                       // material.rs:59-61
+            // graphics.rs:446-451 reads the glTF sampler's wrap / filter modes and then builds a default
+            // sampler (clamp-to-edge, todo.md:6).  Without the reference's quirks the wrap mode is honoured
+            // (glTF default: repeat, 10497).
+            bool repeat = false;
+            if (!renderer.ref_quirks()) {
+                int64_t ws = 10497, wt = 10497;
+                if (tex.has("sampler")) {
+                    const Json &smp = doc.at("samplers").at((size_t)tex.get_int("sampler", 0));
+                    ws = smp.get_int("wrapS", 10497); wt = smp.get_int("wrapT", 10497);
+                }
+                repeat = ws == 10497 && wt == 10497;
+                if (repeat) ident += "#repeat";
+            }
             // gltf::image::Data::from_source decodes on every call (material.rs:64-65); the
             // renderer's ident cache then skips the upload (graphics.rs:396-398).  Decoding is
             // skipped here when the ident is cached -- same result, less work.
@@ -129,12 +142,23 @@ Material material_from_gltf(const Json &doc, const Json *gltf_mat, Renderer &ren
                     }
                     px = rgba.data();
                 }
-                t.bindless_indice = renderer.add_texture(px, img.width, img.height, true);   // R8G8B8A8_SRGB
+                t.bindless_indice = renderer.add_texture(px, img.width, img.height, true, repeat);   // R8G8B8A8_SRGB
                 renderer.add_texture_to_lookup_map(ident, t);
             }
             m.has_base_texture = true;
             m.base_texture_indice = t.bindless_indice;
         }
+    }
+    if (gltf_mat) {
+        // build extension: emission / transmission / ior (ignored by the reference and by its integrator)
+        float strength = 1.0f;
+        if (const Json *x = gltf_mat->find("extensions")) {
+            if (const Json *es = x->find("KHR_materials_emissive_strength")) strength = (float)es->get_number("emissiveStrength", 1.0);
+            if (const Json *tr = x->find("KHR_materials_transmission")) m.transmission = (float)tr->get_number("transmissionFactor", 0.0);
+            if (const Json *io = x->find("KHR_materials_ior")) m.ior = (float)io->get_number("ior", 1.5);
+        }
+        if (const Json *ef = gltf_mat->find("emissiveFactor"))
+            for (int i = 0; i < 3 && i < (int)ef->size(); ++i) m.emissive[i] = (float)ef->at((size_t)i).number(0.0) * strength;
     }
     ptx_material sm;
     memcpy(sm.base_color, m.base_color, sizeof sm.base_color);
@@ -142,6 +166,9 @@ Material material_from_gltf(const Json &doc, const Json *gltf_mat, Renderer &ren
     sm.base_texture_indice = m.base_texture_indice;
     sm.metallic = m.metallic; sm.roughness = m.roughness;
     m.shared_buffer_index = renderer.scene.add_material(sm);
+    ptx_material_ext ext; memset(&ext, 0, sizeof ext);
+    memcpy(ext.emissive, m.emissive, 12); ext.transmission = m.transmission; ext.ior = m.ior;
+    renderer.scene.set_material_ext(m.shared_buffer_index, ext);
     return m;
 }
 
@@ -187,6 +214,13 @@ std::pair<uint64_t, uint64_t> Scene::add_indices(const std::vector<uint32_t> &i)
     if (ptx_add_indices(ctx_, i.data(), i.size(), &first)) ptx_throw(ctx_, "Index buffer overflow");     // scene/mod.rs:412-414
     indices.insert(indices.end(), i.begin(), i.end());
     return {first, first + i.size()};
+}
+
+void Scene::set_material_ext(uint64_t index, const ptx_material_ext &e)
+{
+    if (ptx_set_material_ext(ctx_, (uint32_t)index, &e)) ptx_throw(ctx_, "set_material_ext");
+    if (material_ext.size() <= index) material_ext.resize(index + 1);
+    material_ext[index] = e;
 }
 
 uint64_t Scene::add_material(const ptx_material &m)
@@ -260,14 +294,29 @@ void Scene::import_gltf(Renderer &renderer, const std::string &path, Vec3 positi
     for (size_t si = 0; si < scenes->size(); ++si) {
         const Json *nodes = scenes->at(si).find("nodes");
         if (!nodes) continue;
-        for (size_t ni = 0; ni < nodes->size(); ++ni) {                           // root nodes only, gltf.rs:32-34
-            const Json &node = doc.at("nodes").at((size_t)nodes->at(ni).number(0));
+        // root nodes only (gltf.rs:32-34); without the reference's quirks the children follow their parent
+        // depth first with the composed transform
+        struct Work { size_t node; bool has_parent; Vec3 pt; Quat pr; Vec3 ps; };
+        std::vector<Work> work;
+        for (size_t ni = nodes->size(); ni-- > 0;) work.push_back({(size_t)nodes->at(ni).number(0), false, Vec3(0, 0, 0), Quat{}, Vec3(1, 1, 1)});
+        while (!work.empty()) {
+            Work w = work.back(); work.pop_back();
+            const Json &node = doc.at("nodes").at(w.node);
+            Vec3 t, sc; Quat r;
+            node_trs(node, t, r, sc);
+            if (!renderer.ref_quirks()) {
+                if (w.has_parent) {     // parent * child for TRS triples (exact for uniformly scaled parents)
+                    t = w.pt + w.pr.mul_vec3(Vec3(w.ps.x * t.x, w.ps.y * t.y, w.ps.z * t.z));
+                    r = w.pr.mul(r);
+                    sc = Vec3(w.ps.x * sc.x, w.ps.y * sc.y, w.ps.z * sc.z);
+                }
+                if (const Json *ch = node.find("children"))
+                    for (size_t ci = ch->size(); ci-- > 0;) work.push_back({(size_t)ch->at(ci).number(0), true, t, r, sc});
+            }
             if (!node.has("mesh")) continue;
             size_t mesh_index = (size_t)node.get_int("mesh", 0);
             const Json &mesh = doc.at("meshes").at(mesh_index);
             Transform transform;
-            Vec3 t, sc; Quat r;
-            node_trs(node, t, r, sc);
             transform.position = t + position_offset;                            // gltf.rs:39-41
             transform.rotation = r;
             transform.scale = sc;

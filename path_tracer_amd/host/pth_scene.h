@@ -47,6 +47,10 @@ struct Material {
     bool has_base_texture = false;
     uint32_t base_texture_indice = 0;
     float metallic = 1.0f, roughness = 1.0f;
+    // build extension: what glTF carries beyond material.rs:13-24; sent with ptx_set_material_ext
+    float emissive[3] = {0, 0, 0};      // emissiveFactor x KHR_materials_emissive_strength
+    float transmission = 0.0f;          // KHR_materials_transmission
+    float ior = 1.5f;                   // KHR_materials_ior
     uint64_t get_shared_buffer_offset() const { return shared_buffer_index; }
 };
 
@@ -76,6 +80,7 @@ public:
     std::pair<uint64_t, uint64_t> add_vertices(const std::vector<ptx_vertex> &v);
     std::pair<uint64_t, uint64_t> add_indices(const std::vector<uint32_t> &i);
     uint64_t add_material(const ptx_material &m);
+    void set_material_ext(uint64_t index, const ptx_material_ext &e);   // build extension
 
     const Geometry *get_geometry(const std::string &ident) const;
     void add_geometry(const std::string &ident, const Geometry &g) { geometries_[ident] = g; }
@@ -97,6 +102,7 @@ public:
     std::vector<ptx_vertex> vertices;
     std::vector<uint32_t> indices;
     std::vector<ptx_material> materials;
+    std::vector<ptx_material_ext> material_ext;
 
 private:
     ptx_context *ctx_;

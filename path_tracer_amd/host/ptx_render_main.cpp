@@ -37,7 +37,9 @@ void usage()
             "  --fov DEG        vertical field of view (70)\n"
             "  --gpus N         GPUs, samples split evenly (1)\n"
             "  --out PREFIX     output prefix (render); existing files are not overwritten\n"
-            "  --no-pfm         write only the PNG\n");
+            "  --no-pfm         write only the PNG\n"
+            "  --no-ref-quirks  world-space normals, texel x baseColorFactor, child nodes, sampler wrap modes\n"
+            "  --lit            lit integrator (emissive triangles + next-event estimation + GGX / glass); implies --no-ref-quirks\n");
 }
 
 bool parse3(const char *s, float v[3]) { return sscanf(s, "%f,%f,%f", &v[0], &v[1], &v[2]) == 3; }
@@ -66,7 +68,7 @@ int main(int argc, char **argv)
     uint32_t W = 1280, H = 720, spp = 16, seed = 0x1234567u, depth = 16;
     float cam[3] = {-1.5f, 1.0f, 5.0f}, yaw = 0.0f, fov = 70.0f;
     int gpus = 1;
-    bool pfm = true;
+    bool pfm = true, ref_quirks = true, lit = false;
     std::string out = "render";
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -84,6 +86,8 @@ int main(int argc, char **argv)
         else if (a == "--gpus") gpus = atoi(need("--gpus"));
         else if (a == "--out") out = need("--out");
         else if (a == "--no-pfm") pfm = false;
+        else if (a == "--no-ref-quirks") ref_quirks = false;
+        else if (a == "--lit") { lit = true; ref_quirks = false; }
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else if (a.size() && a[0] == '-') { fprintf(stderr, "unknown option %s\n", a.c_str()); usage(); return 2; }
         else {
@@ -102,6 +106,8 @@ int main(int argc, char **argv)
         for (int g = 0; g < gpus; ++g) {
             rs.emplace_back(new pth::Renderer(W, H, g));
             pth::Renderer &r = *rs.back();
+            if (!ref_quirks) r.set_ref_quirks(false);
+            if (lit) r.params.integrator = PTX_INTEGRATOR_LIT;
             for (const SceneArg &s : scenes) pth::Scene::import_gltf(r, s.path, pth::Vec3(s.off[0], s.off[1], s.off[2]));
             r.camera.transform.position = pth::Vec3(cam[0], cam[1], cam[2]);
             float h = yaw * (3.14159265358979323846f / 180.0f) * 0.5f;

@@ -9,10 +9,10 @@ ASSETS = os.path.join(ROOT, "assets")
 SEED = 0x1234567
 
 
-def ingest(*items, decode_image=None):
+def ingest(*items, decode_image=None, ref_quirks=True):
     """items: (gltf path relative to assets/, position offset)"""
     from oracle.gltf_ingest import IngestedScene
-    ing = IngestedScene()
+    ing = IngestedScene(ref_quirks=ref_quirks)
     for rel, off in items:
         ing.import_gltf(os.path.join(ASSETS, rel), off, decode_image=decode_image)
     return ing
@@ -20,6 +20,11 @@ def ingest(*items, decode_image=None):
 
 def cornell():
     return ingest(("cornell/cornell.gltf", (0, 0, 0)))
+
+
+def cornell_lit():
+    # tools/make_cornell_lit.py: emissive ceiling quad, glass short box, rough-metal tall box
+    return ingest(("cornell_lit/cornell_lit.gltf", (0, 0, 0)), ref_quirks=False)
 
 
 def lion_boulder():
@@ -74,13 +79,17 @@ def stress_scene(n_textures=70, n_confetti=12000, n_layers=24, seed=7):
     return ing
 
 
-def upload(ctx, ing, oracle):
+def upload(ctx, ing, oracle, options=0, with_material_ext=False):
     """Drives the C ABI the way the reference's loaders drive Scene/Renderer."""
     from path_tracer_amd import capi
+    if options:
+        ctx.set_scene_options(options)
     for rgba, srgb in ing.textures:
         ctx.add_texture(rgba, srgb)
-    for m in ing.materials:
-        ctx.add_material(m)
+    for i, m in enumerate(ing.materials):
+        mi = ctx.add_material(m)
+        if with_material_ext:
+            ctx.set_material_ext(mi, ing.material_ext[i])
     geoms = {}
     for ident, (gid, v_first, v_count, i_first, i_count) in ing.geometries.items():
         fv = ctx.add_vertices(ing.vertices[v_first:v_first + v_count])

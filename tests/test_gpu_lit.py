@@ -1,0 +1,185 @@
+"""GPU parity of the build extensions past the reference: the lit integrator
+(emissive triangles, next-event estimation with any-hit occlusion rays, GGX / glass BSDFs, Russian
+roulette) and the no-ref-quirks scene options, HIP path through the C ABI vs oracle/pt_oracle.c
+(raygen_pixel_lit is the specification).  Bar: bit-exact, ids / G-buffers / RGBA32F radiance."""
+import numpy as np
+import pytest
+
+from helpers import SEED, assert_images_bit_equal, cornell, cornell_lit, gpu_render, lion_boulder, stress_scene, upload
+
+pytestmark = pytest.mark.gpu
+
+
+def cam_cornell(oracle, aspect=1.0):
+    return oracle.camera_matrices([0, 1.0, 3.9], oracle.yaw_quat(0), np.deg2rad(np.float32(40)), aspect, 0.1, 1000.0)
+
+
+@pytest.fixture(scope="module")
+def lit_pair(oracle, gpu_ctx_factory):
+    from path_tracer_amd import capi
+    ing = cornell_lit()
+    ctx = gpu_ctx_factory()
+    upload(ctx, ing, oracle, options=capi.SCENE_WORLD_NORMALS | capi.SCENE_TEXTURE_TIMES_FACTOR, with_material_ext=True)
+    sc = oracle.scene_from_ingest(ing, options=oracle.SCENE_WORLD_NORMALS | oracle.SCENE_TEXTURE_TIMES_FACTOR,
+                                  with_material_ext=True)
+    return sc, ctx
+
+
+def test_lit_cornell_64_bit_exact(oracle, lit_pair):
+    from path_tracer_amd import capi
+    sc, ctx = lit_pair
+    assert len(sc.lights()) == 2
+    cam = cam_cornell(oracle)
+    ctx.reset_stats()
+    want = sc.render(cam, 64, 64, 8, SEED, params=oracle.default_params(max_depth=8, flags=1, integrator=oracle.INTEGRATOR_LIT))
+    got = gpu_render(ctx, oracle, cam, 64, 64, 8, params=capi.default_params(max_depth=8, integrator=capi.INTEGRATOR_LIT))
+    assert_images_bit_equal(got, want, "lit cornell 64x64x8")
+    st = ctx.stats()
+    assert st["lights"] == 2
+    assert st["rays"] == want["stats"]["rays"] and st["hits"] == want["stats"]["hits"]
+    assert st["shadow_rays"] == want["stats"]["shadow_rays"] > 0
+    # the light is visible and the box is lit by it
+    assert got["albedo"][..., :3].max() > 5.0 and np.isfinite(got["albedo"]).all()
+
+
+def test_lit_cornell_384_depth16_bit_exact(oracle, lit_pair):
+    from path_tracer_amd import capi
+    sc, ctx = lit_pair
+    cam = cam_cornell(oracle, 384 / 256)
+    want = sc.render(cam, 384, 256, 3, SEED, params=oracle.default_params(integrator=oracle.INTEGRATOR_LIT))
+    got = gpu_render(ctx, oracle, cam, 384, 256, 3, params=capi.default_params(integrator=capi.INTEGRATOR_LIT))
+    assert_images_bit_equal(got, want, "lit cornell 384x256x3 depth 16")
+
+
+def test_lit_batch_equals_repeated_and_resumes(oracle, lit_pair):
+    from path_tracer_amd import capi
+    sc, ctx = lit_pair
+    cam = cam_cornell(oracle)
+    p = capi.default_params(max_depth=6, integrator=capi.INTEGRATOR_LIT)
+    a = gpu_render(ctx, oracle, cam, 80, 48, 5, params=p, batch=True)
+    b = gpu_render(ctx, oracle, cam, 80, 48, 5, params=p, batch=False)
+    assert_images_bit_equal(a, b, "lit batch vs 5x render")
+
+
+def test_reference_integrator_unchanged_by_material_ext(oracle, lit_pair, gpu_ctx_factory):
+    """Emission / transmission rows and the light table do not leak into the reference integrator."""
+    from path_tracer_amd import capi
+    sc, ctx = lit_pair
+    cam = cam_cornell(oracle)
+    want = sc.render(cam, 64, 64, 4, SEED, params=oracle.default_params(max_depth=8))
+    got = gpu_render(ctx, oracle, cam, 64, 64, 4, params=capi.default_params(max_depth=8))
+    assert_images_bit_equal(got, want, "reference integrator on the lit scene")
+
+
+def test_world_normals_option_reference_integrator(oracle, gpu_ctx_factory):
+    """PTX_SCENE_WORLD_NORMALS: the Cornell box is rotated -90 deg about X (cornell.gltf:26-31), so its
+    object-space normals are wrong in the reference; with the option the floor's normal is +Y."""
+    from path_tracer_amd import capi
+    ing = cornell()
+    ctx = gpu_ctx_factory()
+    upload(ctx, ing, oracle, options=capi.SCENE_WORLD_NORMALS)
+    sc = oracle.scene_from_ingest(ing, options=oracle.SCENE_WORLD_NORMALS)
+    cam = cam_cornell(oracle)
+    want = sc.render(cam, 64, 64, 4, SEED, params=oracle.default_params(max_depth=8))
+    got = gpu_render(ctx, oracle, cam, 64, 64, 4, params=capi.default_params(max_depth=8))
+    assert_images_bit_equal(got, want, "cornell, world normals")
+    n = got["normal"][60, 32, :3]          # a floor pixel
+    assert abs(n[1]) > 0.99, n
+    plain = oracle.scene_from_ingest(ing).render(cam, 64, 64, 1, SEED, params=oracle.default_params(max_depth=8))
+    assert abs(plain["normal"][60, 32, 1]) < 0.1        # the reference's object-space normal there
+
+
+def test_textured_lit_and_texture_options(oracle, gpu_ctx_factory):
+    """lion + boulder (2k textures, no emitters: sky light only) through the lit integrator, with texel x
+    factor; and the stress scene's 70 textures with wrap = repeat on the odd ones, reference integrator."""
+    from path_tracer_amd import capi
+    opts = capi.SCENE_WORLD_NORMALS | capi.SCENE_TEXTURE_TIMES_FACTOR
+    ing = lion_boulder()
+    ctx = gpu_ctx_factory()
+    upload(ctx, ing, oracle, options=opts, with_material_ext=True)
+    sc = oracle.scene_from_ingest(ing, options=opts, with_material_ext=True)
+    cam = oracle.camera_matrices([2.0, 0.25, 0.6], oracle.yaw_quat(0), np.deg2rad(np.float32(70)), 320 / 180, 0.1, 1000.0)
+    want = sc.render(cam, 320, 180, 3, SEED, params=oracle.default_params(max_depth=8, integrator=oracle.INTEGRATOR_LIT))
+    got = gpu_render(ctx, oracle, cam, 320, 180, 3, params=capi.default_params(max_depth=8, integrator=capi.INTEGRATOR_LIT))
+    assert_images_bit_equal(got, want, "lit lion+boulder")
+    assert want["stats"]["textured_hits"] > 0 and want["stats"]["shadow_rays"] == 0
+
+    ing = stress_scene()
+    ing.textures = [(rgba, flags | (2 if i % 2 else 0)) for i, (rgba, flags) in enumerate(ing.textures)]
+    ctx = gpu_ctx_factory()
+    upload(ctx, ing, oracle, options=capi.SCENE_TEXTURE_TIMES_FACTOR)
+    sc = oracle.scene_from_ingest(ing, options=oracle.SCENE_TEXTURE_TIMES_FACTOR)
+    cam = oracle.camera_matrices([0.0, 0.2, 4.5], oracle.yaw_quat(0), np.deg2rad(np.float32(60)), 1.0, 0.1, 1000.0)
+    want = sc.render(cam, 128, 128, 2, SEED, params=oracle.default_params(max_depth=5))
+    got = gpu_render(ctx, oracle, cam, 128, 128, 2, params=capi.default_params(max_depth=5))
+    assert_images_bit_equal(got, want, "stress scene, repeat + factor")
+
+
+def test_lit_stress_scene_many_lights(oracle, gpu_ctx_factory):
+    """Thousands of emissive triangles (CDF binary search), mixed metallic / rough / glass materials, ties."""
+    from path_tracer_amd import capi
+    ing = stress_scene(n_confetti=6000)
+    rng = np.random.default_rng(11)
+    for i in range(len(ing.materials)):
+        ing.materials[i]["metallic"] = np.float32([0.0, 1.0, 0.5, 0.0][i % 4])
+        if i % 7 == 0:
+            ing.material_ext[i]["emissive"] = rng.uniform(0.5, 4.0, 3).astype(np.float32)
+        if i % 5 == 1:
+            ing.material_ext[i]["transmission"] = np.float32(0.7)
+            ing.material_ext[i]["ior"] = np.float32(1.33)
+    ctx = gpu_ctx_factory()
+    upload(ctx, ing, oracle, options=capi.SCENE_WORLD_NORMALS, with_material_ext=True)
+    sc = oracle.scene_from_ingest(ing, options=oracle.SCENE_WORLD_NORMALS, with_material_ext=True)
+    assert len(sc.lights()) > 500
+    cam = oracle.camera_matrices([0.0, 0.2, 4.5], oracle.yaw_quat(0), np.deg2rad(np.float32(60)), 1.0, 0.1, 1000.0)
+    want = sc.render(cam, 128, 128, 2, SEED, params=oracle.default_params(max_depth=6, integrator=oracle.INTEGRATOR_LIT))
+    got = gpu_render(ctx, oracle, cam, 128, 128, 2, params=capi.default_params(max_depth=6, integrator=capi.INTEGRATOR_LIT))
+    assert_images_bit_equal(got, want, "lit stress scene")
+    assert ctx.stats()["lights"] == len(sc.lights())
+
+
+def test_extension_error_paths(gpu_ctx_factory):
+    from path_tracer_amd import capi
+    ctx = gpu_ctx_factory()
+    m = np.zeros(1, dtype=capi.MATERIAL_DTYPE)
+    mi = ctx.add_material(m)
+    ext = np.zeros(1, dtype=capi.MATERIAL_EXT_DTYPE)
+    ext["ior"] = 1.5
+    ctx.set_material_ext(mi, ext)
+    with pytest.raises(capi.PtxError):
+        ctx.set_material_ext(mi + 1, ext)
+    bad = ext.copy(); bad["ior"] = 0.0
+    with pytest.raises(capi.PtxError):
+        ctx.set_material_ext(mi, bad)
+    bad = ext.copy(); bad["transmission"] = 1.5
+    with pytest.raises(capi.PtxError):
+        ctx.set_material_ext(mi, bad)
+    with pytest.raises(capi.PtxError):
+        ctx.set_scene_options(4)
+    with pytest.raises(capi.PtxError):
+        ctx.add_texture(np.zeros((2, 2, 4), np.uint8), 8)
+
+
+def test_host_lit_matches_oracle(oracle):
+    """The C++ host mirror with set_ref_quirks(false) + the lit integrator: its glTF import (material
+    extensions, sampler wrap, child nodes) feeds the same scene as the oracle-side ingest."""
+    import os
+    from helpers import ASSETS
+    from path_tracer_amd import capi, host
+    r = host.Renderer(96, 96, 0)
+    r.set_ref_quirks(False)
+    r.import_gltf(os.path.join(ASSETS, "cornell_lit", "cornell_lit.gltf"))
+    fov = np.deg2rad(np.float32(40.0))
+    r.set_camera([0.0, 1.0, 3.9], host.yaw_quat(0.0), fov, 0.1, 1000.0)
+    r.set_seed(SEED, fixed=True)
+    r.set_params(capi.default_params(max_depth=8, integrator=capi.INTEGRATOR_LIT))
+    r.record_commands()          # dirty frame, overwritten (renderer.rs:988-1031)
+    r.record_commands()
+    r.record_commands_batch(4)
+    got = {k: r.read_image(v) for k, v in (("albedo", capi.IMAGE_ALBEDO), ("normal", capi.IMAGE_NORMAL),
+                                           ("depth", capi.IMAGE_DEPTH), ("ids", capi.IMAGE_PRIMARY_ID))}
+    sc = oracle.scene_from_ingest(cornell_lit(), options=oracle.SCENE_WORLD_NORMALS | oracle.SCENE_TEXTURE_TIMES_FACTOR,
+                                  with_material_ext=True)
+    want = sc.render(cam_cornell(oracle), 96, 96, 4, SEED, params=oracle.default_params(max_depth=8, integrator=oracle.INTEGRATOR_LIT))
+    assert_images_bit_equal(got, want, "host lit cornell")
+    r.close()
