@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--spp-per-step", type=int, default=16)
     ap.add_argument("--workload", default="sponza_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--max-depth", type=int, default=16)
+    ap.add_argument("--integrator", default="reference", choices=["reference", "lit"],
+                    help="reference: the reference's rchit/rmiss shading (the headline number); lit: the build's "
+                         "extension with emissive triangles + next-event estimation + GGX/glass BSDFs (SURVEY 8f.3)")
     ap.add_argument("--cpu-baseline-spp", type=int, default=2, help="0 disables the CPU leg")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
     args = ap.parse_args()
@@ -79,15 +82,22 @@ def main():
     limits = capi.default_limits(max_vertices=10 ** 7, max_indices=3 * 10 ** 7)
     t0 = time.time()
     r = host.Renderer(W, H, local_rank, limits)
+    lit = args.integrator == "lit"
+    if lit:
+        r.set_ref_quirks(False)       # world-space normals, texel x factor, sampler wrap modes, child nodes
     for rel, off in wl["items"]:
         r.import_gltf(os.path.join(assets, rel), off)
+    if lit:
+        for row, ext in lit_emitters(args.workload, r.scene_arrays()[2]):
+            r._ctx().set_material_ext(row, ext)
     r.set_camera(wl["pos"], host.yaw_quat(wl["yaw"]), np.deg2rad(np.float32(wl["fov"])), 0.1, 1000.0)
     r.set_seed(SEED, fixed=True)
     from path_tracer_amd.multi_gpu import combine_accumulation, partition_samples
     spp = args.spp_per_step
     # the job's budget is world x (steps + warmup) x spp samples per pixel; rank g renders slice g of it
     first_sample, _ = partition_samples(world * (args.steps + args.warmup) * spp, world, rank)
-    params = capi.default_params(max_depth=args.max_depth, rng_sample_offset=first_sample)
+    params = capi.default_params(max_depth=args.max_depth, rng_sample_offset=first_sample,
+                                 integrator=capi.INTEGRATOR_LIT if lit else capi.INTEGRATOR_REFERENCE)
     r.set_params(params)
     ctx = r._ctx()
     for _ in range(args.warmup):
@@ -183,7 +193,7 @@ def main():
         cpu = None
         parity = None
         if args.cpu_baseline_spp > 0:
-            cpu, parity = cpu_baseline(r, wl, assets, W, H, args.cpu_baseline_spp, args.max_depth)
+            cpu, parity = cpu_baseline(r, wl, assets, W, H, args.cpu_baseline_spp, args.max_depth, args.workload, lit)
 
         out = {
             "metric": "samples/sec (Mrays/s) Sponza 1080p at 1/2/4/8 MI355X; rel-MSE vs ref",
@@ -193,12 +203,14 @@ def main():
             "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "resolution": "%dx%d" % (W, H), "spp_per_step": spp,
+            "config": {"workload": args.workload + ("+lit" if lit else ""), "integrator": args.integrator,
+                       "resolution": "%dx%d" % (W, H), "spp_per_step": spp,
                        "max_depth": args.max_depth, "seed": SEED, "geometry": wl["geometry"],
                        "parallelism": "spp-partition x%d, scene+BVH replicated, one RCCL reduce" % world if world > 1 else "single GPU",
                        "triangles": int(st["bvh_triangles"]), "bvh_nodes": int(st["bvh_nodes"])},
             "mrays_per_s": round(job_rays / elapsed / 1e6, 1),
             "rays_per_sample": round(job_rays / max(1.0, job_samples), 3),
+            "shadow_rays_per_sample": round(st["shadow_rays"] / max(1, st["samples"]), 3), "lights": int(st["lights"]),
             "scene_load_s": round(load_s, 2),
             "roofline": roofline,
             "cpu_baseline": cpu,
@@ -212,27 +224,51 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(r, wl, assets, W, H, spp, max_depth):
+def lit_emitters(workload, materials):
+    """(material row, ptx_material_ext) pairs that turn a workload's scene into one with light sources: none of the
+    reference's assets has an emitter.  Sponza: the 8 small primitives of glTF material 3 (one material row per
+    primitive, material.rs:34-90) glow warm; other scenes keep the sky as their only light."""
+    from path_tracer_amd import capi
+    out = []
+    if workload.startswith("sponza"):
+        doc = json.load(open(os.path.join(ROOT, "assets", "sponza", "Sponza.gltf")))
+        for row, prim in enumerate(doc["meshes"][0]["primitives"]):
+            if prim.get("material") == 3 and row < len(materials):
+                e = np.zeros(1, dtype=capi.MATERIAL_EXT_DTYPE)
+                e["emissive"] = [24.0, 18.0, 10.0]
+                e["ior"] = 1.5
+                out.append((row, e))
+    return out
+
+
+def cpu_baseline(r, wl, assets, W, H, spp, max_depth, workload, lit):
     """Times the CPU oracle (oracle/pt_oracle.c, a port of the reference's shaders -- the reference itself
     has no CPU path) on a bounded sample of the same workload, and checks the GPU image against it."""
     from oracle import pyoracle as O
     from oracle.gltf_ingest import IngestedScene
     from path_tracer_amd import capi, host
-    ing = IngestedScene()
+    ing = IngestedScene(ref_quirks=not lit)
     for rel, off in wl["items"]:
         ing.import_gltf(os.path.join(assets, rel), off, decode_image=host.decode_image)   # same texels as the GPU side
-    sc = O.scene_from_ingest(ing)
+    if lit:
+        for row, ext in lit_emitters(workload, ing.materials):
+            ing.material_ext[row] = ext[0]
+        sc = O.scene_from_ingest(ing, options=O.SCENE_WORLD_NORMALS | O.SCENE_TEXTURE_TIMES_FACTOR, with_material_ext=True)
+    else:
+        sc = O.scene_from_ingest(ing)
+    integ = O.INTEGRATOR_LIT if lit else O.INTEGRATOR_REFERENCE
+    ginteg = capi.INTEGRATOR_LIT if lit else capi.INTEGRATOR_REFERENCE
     cam = O.camera_matrices(wl["pos"], O.yaw_quat(wl["yaw"]), np.deg2rad(np.float32(wl["fov"])), W / H, 0.1, 1000.0)
     threads = min(os.cpu_count() or 1, 16)
     t = time.perf_counter()
-    want = sc.render(cam, W, H, spp, SEED, params=O.default_params(max_depth=max_depth), threads=threads)
+    want = sc.render(cam, W, H, spp, SEED, params=O.default_params(max_depth=max_depth, integrator=integ), threads=threads)
     dt = time.perf_counter() - t
     # the same spp frames on the GPU, from a fresh accumulation, through the C ABI
     ctx = r._ctx()
     ctx.resize(W, H)
     gcam = host.camera_matrices(wl["pos"], host.yaw_quat(wl["yaw"]), np.deg2rad(np.float32(wl["fov"])), W / H, 0.1, 1000.0)
     u = capi.Uniforms(1, SEED, 0, 0.1, 100.0, (0, 0, 0))
-    ctx.render_batch(u, gcam, spp, capi.default_params(max_depth=max_depth))
+    ctx.render_batch(u, gcam, spp, capi.default_params(max_depth=max_depth, integrator=ginteg))
     got = ctx.read_image(capi.IMAGE_ALBEDO)
     ids = ctx.read_image(capi.IMAGE_PRIMARY_ID)
     a = np.asarray(got, np.float64)[..., :3]
