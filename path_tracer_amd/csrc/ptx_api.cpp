@@ -29,6 +29,21 @@ struct Geometry { uint64_t first_vertex, n_vertices, first_index, n_indices; };
 
 struct EventPair { hipEvent_t a, b; int kind; };   // kind 0 extend, 1 shade, 2 whole render call
 
+// Wavefront state of one chunk of paths in flight.  Consecutive chunks (frames of the interactive loop,
+// chunks of a batch) go to different sets on different streams, so the thin tail of one chunk's late
+// bounces overlaps the next chunk's wide early ones; their resolves are chained by events, so the image
+// receives its samples in accumulated_count order exactly as with one stream.
+constexpr int kMaxSets = 4;
+struct PathSet {
+    hipStream_t stream = nullptr;
+    uint64_t capacity = 0;
+    void *d_rays[3] = {nullptr, nullptr, nullptr};   // two ray queues (four 16-byte planes each), ping-pong per bounce; [2]: occlusion rays (lit integrator, allocated on first use)
+    HitOut *d_hits = nullptr;
+    float4 *d_results = nullptr;
+    uint32_t *d_counters = nullptr;
+    hipEvent_t resolved = nullptr;                   // recorded after the set's latest resolve
+};
+
 }  // namespace
 
 struct ptx_context {
@@ -64,13 +79,14 @@ struct ptx_context {
     float4 *d_albedo = nullptr, *d_normal = nullptr; float *d_depth = nullptr; uint2 *d_ids = nullptr;
 
     // wavefront state
-    uint64_t path_capacity = 0;
     uint64_t target_paths = 32u << 20;
     uint32_t extend_waves = 4096;           // persistent grid of the traversal kernel
-    void *d_rays[3] = {nullptr, nullptr, nullptr};   // two ray queues (four 16-byte planes each), ping-pong per bounce; [2]: occlusion rays (lit integrator, allocated on first use)
-    HitOut *d_hits = nullptr;
-    float4 *d_results = nullptr;
-    uint32_t *d_counters = nullptr;
+    PathSet sets[kMaxSets];
+    int n_sets = 2;                         // chunks in flight (PTX_FRAMES_IN_FLIGHT; measured: 2 gives the whole gain, 3 is slower than 2 and 4)
+    int next_set = 0;
+    hipEvent_t last_resolved = nullptr;     // = sets[k].resolved of the most recent chunk: the next resolve waits for it
+    bool have_last_frame = false;           // camera / frame parameters of the previous render call
+    ptx_camera last_cam{};
     uint64_t *d_totals = nullptr;           // rays, hits, samples, nodes fetched, triangles tested
 
     // profiling
@@ -105,28 +121,39 @@ int bind(ptx_context *c)
 
 template <class T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
-void free_paths(ptx_context *c)
+void free_paths(PathSet &ps)
 {
-    dfree(c->d_rays[0]); dfree(c->d_rays[1]); dfree(c->d_rays[2]); dfree(c->d_hits); dfree(c->d_results);
-    c->path_capacity = 0;
+    dfree(ps.d_rays[0]); dfree(ps.d_rays[1]); dfree(ps.d_rays[2]); dfree(ps.d_hits); dfree(ps.d_results);
+    ps.capacity = 0;
 }
 
-int ensure_paths(ptx_context *c, uint64_t n)
+// the set's stream must be idle (its buffers may be replaced)
+int ensure_paths(ptx_context *c, PathSet &ps, uint64_t n, bool shadow_queue)
 {
-    if (n <= c->path_capacity) return PTX_OK;
-    free_paths(c);
-    HIP_TRY(c, hipMalloc(&c->d_rays[0], n * kRayBytes));
-    HIP_TRY(c, hipMalloc(&c->d_rays[1], n * kRayBytes));
-    HIP_TRY(c, hipMalloc((void **)&c->d_hits, n * sizeof(HitOut)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_results, n * sizeof(float4)));
-    c->path_capacity = n;
+    if (!ps.stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&ps.stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&ps.resolved, hipEventDisableTiming));
+        HIP_TRY(c, hipMalloc((void **)&ps.d_counters, kNumCounters * sizeof(uint32_t)));
+    }
+    if (n > ps.capacity) {
+        HIP_TRY(c, hipStreamSynchronize(ps.stream));
+        free_paths(ps);
+        HIP_TRY(c, hipMalloc(&ps.d_rays[0], n * kRayBytes));
+        HIP_TRY(c, hipMalloc(&ps.d_rays[1], n * kRayBytes));
+        HIP_TRY(c, hipMalloc((void **)&ps.d_hits, n * sizeof(HitOut)));
+        HIP_TRY(c, hipMalloc((void **)&ps.d_results, n * sizeof(float4)));
+        ps.capacity = n;
+    }
+    if (shadow_queue && !ps.d_rays[2]) HIP_TRY(c, hipMalloc(&ps.d_rays[2], ps.capacity * kRayBytes));
     return PTX_OK;
 }
 
-int ensure_shadow_queue(ptx_context *c)
+// every stream of the context idle
+int sync_all(ptx_context *c)
 {
-    if (c->d_rays[2]) return PTX_OK;
-    HIP_TRY(c, hipMalloc(&c->d_rays[2], c->path_capacity * kRayBytes));
+    for (int i = 0; i < kMaxSets; ++i)
+        if (c->sets[i].stream) HIP_TRY(c, hipStreamSynchronize(c->sets[i].stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return PTX_OK;
 }
 
@@ -239,7 +266,7 @@ int ptx_create_with_limits(int device_ordinal, const ptx_limits *limits, ptx_con
     } while (0)
     CREATE_TRY(hipSetDevice(device_ordinal));
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CREATE_TRY(hipMalloc((void **)&c->d_counters, kNumCounters * sizeof(uint32_t)));
+    if (const char *fi = getenv("PTX_FRAMES_IN_FLIGHT")) { long v = strtol(fi, nullptr, 10); if (v >= 1 && v <= kMaxSets) c->n_sets = (int)v; }
     CREATE_TRY(hipMalloc((void **)&c->d_totals, kNumTotals * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->d_totals, 0, kNumTotals * sizeof(uint64_t)));
     CREATE_TRY(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
@@ -258,15 +285,21 @@ int ptx_destroy(ptx_context *c)
 {
     if (!c) return PTX_OK;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     drain_events(c);
     for (EventPair &p : c->event_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (TexDesc &t : c->textures) { void *p = (void *)t.texels; if (p) (void)hipFree(p); }
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_textures); dfree(c->d_lut);
     dfree(c->d_lit_materials); dfree(c->d_lights); dfree(c->d_light_cdf);
     dfree(c->d_albedo); dfree(c->d_normal); dfree(c->d_depth); dfree(c->d_ids);
-    free_paths(c);
-    dfree(c->d_counters); dfree(c->d_totals);
+    for (int i = 0; i < kMaxSets; ++i) {
+        PathSet &ps = c->sets[i];
+        free_paths(ps);
+        dfree(ps.d_counters);
+        if (ps.resolved) (void)hipEventDestroy(ps.resolved);
+        if (ps.stream) (void)hipStreamDestroy(ps.stream);
+    }
+    dfree(c->d_totals);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PTX_OK;
@@ -496,7 +529,7 @@ int ptx_set_instances(ptx_context *c, const ptx_instance *inst, uint32_t n)
         memcpy(sr.uv0, a.uv, 8); memcpy(sr.uv1, b.uv, 8); memcpy(sr.uv2, d.uv, 8);
     }
 
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int r = sync_all(c)) return r;
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade);
     dfree(c->d_lit_materials); dfree(c->d_lights); dfree(c->d_light_cdf);
     c->n_lights = 0;
@@ -542,7 +575,8 @@ int ptx_resize(ptx_context *c, uint32_t w, uint32_t h)
     if (!c) return PTX_ERR_INVALID;
     if (w == 0 || h == 0 || (uint64_t)w * h > 0x40000000ull) return fail(c, PTX_ERR_INVALID, "ptx_resize: bad extent");
     if (int r = bind(c)) return r;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int r = sync_all(c)) return r;
+    c->have_last_frame = false;
     dfree(c->d_albedo); dfree(c->d_normal); dfree(c->d_depth); dfree(c->d_ids);
     c->width = c->height = 0;
     uint64_t np = (uint64_t)w * h;
@@ -578,8 +612,6 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
     uint64_t chunk = std::max<uint64_t>(1, c->target_paths / npix);
     chunk = std::min<uint64_t>(chunk, n_samples);
     if (chunk * npix > 0xFFFFFF00ull) chunk = 0xFFFFFF00ull / npix;
-    if (int r = ensure_paths(c, chunk * npix)) return r;
-    if (lit) if (int r = ensure_shadow_queue(c)) return r;
 
     SceneDev sc;
     sc.lit_materials = c->d_lit_materials; sc.lights = c->d_lights; sc.light_cdf = c->d_light_cdf; sc.n_lights = c->n_lights;
@@ -595,45 +627,60 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
     f.tex_times_factor = (c->built_options & PTX_SCENE_TEXTURE_TIMES_FACTOR) ? 1u : 0u;
     const uint32_t bounces = std::max(1u, p.max_depth);
 
-    EventPair whole{};
-    if (c->profiling) { whole = get_events(c, 2); HIP_TRY(c, hipEventRecord(whole.a, c->stream)); }
+    // Chunks normally overlap with the chunks before them (other path sets, other streams).  A frame that
+    // rewrites the G-buffers or the id image with NEW content -- accumulated_count 0, or a camera that moved --
+    // first waits for everything before it, so that its writes land last.
+    const bool fresh = u->accumulated_count == 0 || !c->have_last_frame || memcmp(&c->last_cam, cam, sizeof *cam) != 0;
+    c->last_cam = *cam; c->have_last_frame = true;
+
     for (uint32_t s0 = 0; s0 < n_samples; s0 += (uint32_t)chunk) {
         uint32_t ns = (uint32_t)std::min<uint64_t>(chunk, n_samples - s0);
         uint32_t n_paths = (uint32_t)(ns * npix);
+        PathSet &ps = c->sets[c->next_set];
+        c->next_set = (c->next_set + 1) % c->n_sets;
+        if (int r = ensure_paths(c, ps, chunk * npix, lit)) return r;
+        hipStream_t st = ps.stream;
+        if (fresh && s0 == 0 && c->last_resolved) HIP_TRY(c, hipStreamWaitEvent(st, c->last_resolved, 0));
+        EventPair whole{};
+        if (c->profiling) { whole = get_events(c, 2); HIP_TRY(c, hipEventRecord(whole.a, st)); }
         f.mean_base = u->accumulated_count + s0;
         f.ids_sample = (s0 == 0) ? 0u : 0xFFFFFFFFu;
-        launch_raygen(c->stream, f, n_paths, make_ray_queue(c->d_rays[0], c->path_capacity), c->d_counters);
+        launch_raygen(st, f, n_paths, make_ray_queue(ps.d_rays[0], ps.capacity), ps.d_counters);
         for (uint32_t b = 0; b < bounces; ++b) {
-            RayQueue rin = make_ray_queue(c->d_rays[b & 1], c->path_capacity), rout = make_ray_queue(c->d_rays[(b & 1) ^ 1], c->path_capacity);
-            RayQueue shadow_q = make_ray_queue(lit ? c->d_rays[2] : c->d_rays[0], c->path_capacity);
+            RayQueue rin = make_ray_queue(ps.d_rays[b & 1], ps.capacity), rout = make_ray_queue(ps.d_rays[(b & 1) ^ 1], ps.capacity);
+            RayQueue shadow_q = make_ray_queue(lit ? ps.d_rays[2] : ps.d_rays[0], ps.capacity);
             uint64_t *trav = c->count_traversal ? c->d_totals + 3 : nullptr;
             EventPair e{}, e2{};
-            if (c->profiling) { e = get_events(c, 0); HIP_TRY(c, hipEventRecord(e.a, c->stream)); }
-            launch_extend(c->stream, sc, f, rin, c->d_counters + b, c->d_counters + kNextBase + b, n_paths, c->extend_waves, c->d_hits, trav);
+            if (c->profiling) { e = get_events(c, 0); HIP_TRY(c, hipEventRecord(e.a, st)); }
+            launch_extend(st, sc, f, rin, ps.d_counters + b, ps.d_counters + kNextBase + b, n_paths, c->extend_waves, ps.d_hits, trav);
             if (c->profiling) {
-                HIP_TRY(c, hipEventRecord(e.b, c->stream)); c->events.push_back(e);
-                e2 = get_events(c, 1); HIP_TRY(c, hipEventRecord(e2.a, c->stream));
+                HIP_TRY(c, hipEventRecord(e.b, st)); c->events.push_back(e);
+                e2 = get_events(c, 1); HIP_TRY(c, hipEventRecord(e2.a, st));
             }
             if (!lit) {
-                launch_shade(c->stream, sc, f, img, b, rin, c->d_hits, c->d_counters, n_paths, rout, c->d_results);
+                launch_shade(st, sc, f, img, b, rin, ps.d_hits, ps.d_counters, n_paths, rout, ps.d_results);
             } else {
-                launch_shade_lit(c->stream, sc, f, img, b, rin, c->d_hits, c->d_counters, n_paths, rout, shadow_q, c->d_results);
+                launch_shade_lit(st, sc, f, img, b, rin, ps.d_hits, ps.d_counters, n_paths, rout, shadow_q, ps.d_results);
             }
-            if (c->profiling) { HIP_TRY(c, hipEventRecord(e2.b, c->stream)); c->events.push_back(e2); }
+            if (c->profiling) { HIP_TRY(c, hipEventRecord(e2.b, st)); c->events.push_back(e2); }
             if (lit && c->n_lights) {
                 // occlusion rays of this bounce: any-hit traversal, then the unoccluded contributions join the radiance
                 EventPair e3{};
-                if (c->profiling) { e3 = get_events(c, 0); HIP_TRY(c, hipEventRecord(e3.a, c->stream)); }
-                launch_extend(c->stream, sc, f, shadow_q, c->d_counters + kShadowCount + b, c->d_counters + kShadowNext + b, n_paths,
-                              c->extend_waves, c->d_hits, nullptr, true);
-                if (c->profiling) { HIP_TRY(c, hipEventRecord(e3.b, c->stream)); c->events.push_back(e3); }
-                launch_shadow_resolve(c->stream, b, shadow_q, c->d_hits, c->d_counters, n_paths, c->d_results);
+                if (c->profiling) { e3 = get_events(c, 0); HIP_TRY(c, hipEventRecord(e3.a, st)); }
+                launch_extend(st, sc, f, shadow_q, ps.d_counters + kShadowCount + b, ps.d_counters + kShadowNext + b, n_paths,
+                              c->extend_waves, ps.d_hits, nullptr, true);
+                if (c->profiling) { HIP_TRY(c, hipEventRecord(e3.b, st)); c->events.push_back(e3); }
+                launch_shadow_resolve(st, b, shadow_q, ps.d_hits, ps.d_counters, n_paths, ps.d_results);
             }
         }
-        launch_resolve(c->stream, f, img, c->d_results, ns);
-        launch_accumulate_stats(c->stream, c->d_counters, bounces, (uint64_t)n_paths, c->d_totals);
+        // samples join the running mean in accumulated_count order: this chunk's resolve after the previous chunk's
+        if (c->last_resolved && c->last_resolved != ps.resolved) HIP_TRY(c, hipStreamWaitEvent(st, c->last_resolved, 0));
+        launch_resolve(st, f, img, ps.d_results, ns);
+        launch_accumulate_stats(st, ps.d_counters, bounces, (uint64_t)n_paths, c->d_totals);
+        HIP_TRY(c, hipEventRecord(ps.resolved, st));
+        c->last_resolved = ps.resolved;
+        if (c->profiling) { HIP_TRY(c, hipEventRecord(whole.b, st)); c->events.push_back(whole); }
     }
-    if (c->profiling) { HIP_TRY(c, hipEventRecord(whole.b, c->stream)); c->events.push_back(whole); }
     HIP_TRY(c, hipGetLastError());
     return PTX_OK;
 }
@@ -659,6 +706,7 @@ int ptx_read_image(ptx_context *c, int kind, void *dst, uint64_t bytes)
     }
     if (bytes != want) return fail(c, PTX_ERR_INVALID, "ptx_read_image: byte count does not match the image");
     if (int r = bind(c)) return r;
+    if (int r = sync_all(c)) return r;
     HIP_TRY(c, hipMemcpyAsync(dst, src, want, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return PTX_OK;
@@ -671,6 +719,7 @@ int ptx_write_albedo(ptx_context *c, const void *src, uint64_t bytes)
     if (!c->width) return fail(c, PTX_ERR_STATE, "ptx_write_albedo: no image");
     if (bytes != (uint64_t)c->width * c->height * 16) return fail(c, PTX_ERR_INVALID, "ptx_write_albedo: byte count does not match the image");
     if (int r = bind(c)) return r;
+    if (int r = sync_all(c)) return r;
     HIP_TRY(c, hipMemcpyAsync(c->d_albedo, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return PTX_OK;
@@ -684,6 +733,7 @@ int ptx_export_albedo_device(ptx_context *c, void *device_dst, uint64_t bytes, f
     uint64_t np = (uint64_t)c->width * c->height;
     if (bytes != np * 16) return fail(c, PTX_ERR_INVALID, "ptx_export_albedo_device: byte count does not match the image");
     if (int r = bind(c)) return r;
+    if (int r = sync_all(c)) return r;
     launch_scale_copy(c->stream, c->d_albedo, (float4 *)device_dst, np, scale);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -698,6 +748,7 @@ int ptx_import_albedo_device(ptx_context *c, const void *device_src, uint64_t by
     uint64_t np = (uint64_t)c->width * c->height;
     if (bytes != np * 16) return fail(c, PTX_ERR_INVALID, "ptx_import_albedo_device: byte count does not match the image");
     if (int r = bind(c)) return r;
+    if (int r = sync_all(c)) return r;
     launch_scale_copy(c->stream, (const float4 *)device_src, c->d_albedo, np, scale);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -708,8 +759,7 @@ int ptx_synchronize(ptx_context *c)
 {
     if (!c) return PTX_ERR_INVALID;
     if (int r = bind(c)) return r;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return PTX_OK;
+    return sync_all(c);
 }
 
 int ptx_set_profiling(ptx_context *c, int enabled)
@@ -725,7 +775,7 @@ int ptx_get_stats(ptx_context *c, ptx_stats *s)
     if (!c) return PTX_ERR_INVALID;
     if (!s) return fail(c, PTX_ERR_INVALID, "ptx_get_stats: NULL argument");
     if (int r = bind(c)) return r;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int r = sync_all(c)) return r;
     drain_events(c);
     uint64_t t[kNumTotals];
     HIP_TRY(c, hipMemcpy(t, c->d_totals, sizeof t, hipMemcpyDeviceToHost));
@@ -744,7 +794,7 @@ int ptx_reset_stats(ptx_context *c)
 {
     if (!c) return PTX_ERR_INVALID;
     if (int r = bind(c)) return r;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int r = sync_all(c)) return r;
     drain_events(c);
     HIP_TRY(c, hipMemset(c->d_totals, 0, kNumTotals * sizeof(uint64_t)));
     c->extend_ms = c->shade_ms = c->total_ms = 0; c->extend_launches = 0;
