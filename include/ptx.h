@@ -150,6 +150,7 @@ typedef struct {
     uint64_t wave_sched[6];                /* level 2: wave iterations, node blocks, lanes in them, triangle blocks, lanes in them, refills */
     uint64_t shadow_rays;                  /* lit integrator: occlusion queries (not counted in rays) */
     uint64_t lights;                       /* emissive triangles in the light table */
+    uint64_t bvh_builds, bvh_refits;       /* acceleration-structure builds / refits since ptx_create */
 } ptx_stats;
 
 typedef struct ptx_context ptx_context;
@@ -189,6 +190,13 @@ int ptx_create_geometry(ptx_context *ctx, uint64_t first_vertex, uint64_t n_vert
  * Rebuilds the acceleration structure (synchronises the stream).  The caller restarts the
  * accumulation (accumulated_count = 0), as renderer.rs:995-1000 does when the scene is dirty. */
 int ptx_set_instances(ptx_context *ctx, const ptx_instance *instances, uint32_t n);
+
+/* Build extension (todo.md:3 "Stop rebuilding entire AS on every frame"; the reference's unused TLAS update,
+ * renderer.rs:1086-1192): the same instance list as the last ptx_set_instances / ptx_update_instances -- same
+ * geometry handles and Offsets rows -- with new transforms.  Keeps the tree and refits its boxes; falls back to a
+ * full rebuild when the list differs or the moved scene has loosened the tree too far.  Same results as
+ * ptx_set_instances either way (the closest hit does not depend on the tree). */
+int ptx_update_instances(ptx_context *ctx, const ptx_instance *instances, uint32_t n);
 
 /* Renderer::resize_render_buffer (renderer.rs:583): reallocates the three images, resets accumulation. */
 int ptx_resize(ptx_context *ctx, uint32_t width, uint32_t height);

@@ -51,7 +51,7 @@ class Stats(C.Structure):
                 ("total_ms", C.c_double), ("bvh_nodes", C.c_uint64), ("bvh_triangles", C.c_uint64),
                 ("bvh_bytes", C.c_uint64), ("bvh_depth", C.c_uint32), ("_pad", C.c_uint32),
                 ("nodes_fetched", C.c_uint64), ("tris_tested", C.c_uint64), ("wave_sched", C.c_uint64 * 6),
-                ("shadow_rays", C.c_uint64), ("lights", C.c_uint64)]
+                ("shadow_rays", C.c_uint64), ("lights", C.c_uint64), ("bvh_builds", C.c_uint64), ("bvh_refits", C.c_uint64)]
 
 
 EXPORTS = [
@@ -60,7 +60,7 @@ EXPORTS = [
     "ptx_set_instances", "ptx_resize", "ptx_render", "ptx_render_batch", "ptx_read_image", "ptx_write_albedo",
     "ptx_export_albedo_device", "ptx_import_albedo_device", "ptx_reduce_accumulation", "ptx_synchronize",
     "ptx_set_profiling", "ptx_get_stats", "ptx_reset_stats", "ptx_last_error",
-    "ptx_set_material_ext", "ptx_set_scene_options",
+    "ptx_set_material_ext", "ptx_set_scene_options", "ptx_update_instances",
 ]
 
 _lib = None
@@ -95,6 +95,7 @@ def load():
     L.ptx_add_texture.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
     L.ptx_create_geometry.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
     L.ptx_set_instances.argtypes = [vp, vp, C.c_uint32]
+    L.ptx_update_instances.argtypes = [vp, vp, C.c_uint32]
     L.ptx_resize.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.ptx_render.argtypes = [vp, C.POINTER(Uniforms), C.POINTER(Camera), C.POINTER(RenderParams)]
     L.ptx_render_batch.argtypes = [vp, C.POINTER(Uniforms), C.POINTER(Camera), C.POINTER(RenderParams), C.c_uint32]
@@ -198,6 +199,10 @@ class Context:
     def set_instances(self, inst):
         inst = np.ascontiguousarray(inst, dtype=INSTANCE_DTYPE)
         self._check(self._L.ptx_set_instances(self.handle, inst.ctypes.data, len(inst)))
+
+    def update_instances(self, inst):
+        inst = np.ascontiguousarray(inst, dtype=INSTANCE_DTYPE)
+        self._check(self._L.ptx_update_instances(self.handle, inst.ctypes.data, len(inst)))
 
     def resize(self, width, height):
         self._check(self._L.ptx_resize(self.handle, width, height))

@@ -44,4 +44,9 @@ struct Bvh8 {
 // Returns false (and leaves `out` empty) if a coordinate is not finite.
 bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads);
 
+// Same tree, moved triangles (same indexing as the build's input): recomputes every box bottom-up.
+// Returns false if the set of finite triangles changed (the caller rebuilds).  *sah: sum of node
+// half-areas / root half-area, a traversal-cost figure to compare against the freshly built tree's.
+bool refit_bvh8(Bvh8 &bvh, const float *verts, size_t n_tris, double *sah);
+
 }  // namespace ptx

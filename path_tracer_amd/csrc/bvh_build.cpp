@@ -138,6 +138,68 @@ float env_float(const char *name, float dflt)
 
 inline float step_of(uint8_t e) { uint32_t u = (uint32_t)e << 23; float f; memcpy(&f, &u, 4); return f; }
 
+// quantisation frame of a node: origin = low corner, per-axis power-of-two step covering the extent in 255 steps
+void set_node_frame(Bvh8Node &nd, const Box &box)
+{
+    for (int a = 0; a < 3; ++a) {
+        nd.p[a] = box.lo[a];
+        float ext = box.hi[a] - box.lo[a];
+        int e; float m = std::frexp(ext / 255.0f, &e);   // ext/255 = m * 2^e, m in [0.5,1)
+        (void)m;
+        int be = e + 127;                                // step = 2^e >= ext/255
+        be = std::min(254, std::max(1, be));
+        while (be < 254 && !(nd.p[a] + step_of((uint8_t)be) * 255.0f >= box.hi[a])) ++be;
+        nd.e[a] = (uint8_t)be;
+    }
+}
+
+// conservative 8-bit planes of child box `ch` in slot s: the decoded planes (fp32: p + q*step) enclose it
+void set_child_planes(Bvh8Node &nd, int s, const Box &ch)
+{
+    for (int a = 0; a < 3; ++a) {
+        float st = step_of(nd.e[a]);
+        int lo = (int)std::floor(((double)ch.lo[a] - (double)nd.p[a]) / (double)st);
+        int hi = (int)std::ceil(((double)ch.hi[a] - (double)nd.p[a]) / (double)st);
+        lo = std::min(255, std::max(0, lo)); hi = std::min(255, std::max(0, hi));
+        while (lo > 0 && nd.p[a] + (float)lo * st > ch.lo[a]) --lo;
+        while (hi < 255 && nd.p[a] + (float)hi * st < ch.hi[a]) ++hi;
+        nd.qlo[a][s] = (uint8_t)lo; nd.qhi[a][s] = (uint8_t)hi;
+    }
+}
+
+// Boxes of the finite triangles, padded so that box culling can never contradict the triangle test (the
+// test's edge functions are exact only up to a few ulps of the coordinate magnitude).  Returns the indices
+// of the finite triangles; a triangle with a non-finite coordinate can never be hit and is left out.
+std::vector<uint32_t> padded_tri_boxes(const float *verts, size_t n_tris, std::vector<Box> &tri_box)
+{
+    tri_box.resize(n_tris);
+    std::vector<uint32_t> order; order.reserve(n_tris);
+    float scene_ext = 0.0f;
+    Box sb; sb.reset();
+    for (size_t t = 0; t < n_tris; ++t) {
+        const float *v = verts + t * 9;
+        bool fin = true;
+        for (int k = 0; k < 9; ++k) fin = fin && std::isfinite(v[k]);
+        if (!fin) { tri_box[t].reset(); continue; }
+        Box b; b.reset();
+        for (int k = 0; k < 3; ++k)
+            for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], v[k * 3 + a]); b.hi[a] = std::max(b.hi[a], v[k * 3 + a]); }
+        tri_box[t] = b; sb.grow(b);
+        order.push_back((uint32_t)t);
+    }
+    if (order.empty()) return order;
+    for (int a = 0; a < 3; ++a) scene_ext = std::max(scene_ext, sb.hi[a] - sb.lo[a]);
+    for (uint32_t t : order) {
+        Box &b = tri_box[t];
+        for (int a = 0; a < 3; ++a) {
+            float m = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
+            float pad = 2e-5f * m + 1e-6f * scene_ext + 1e-30f;
+            b.lo[a] -= pad; b.hi[a] += pad;
+        }
+    }
+    return order;
+}
+
 }  // namespace
 
 bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
@@ -146,39 +208,12 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
     if (n_tris == 0) return true;
     if (n_tris > 1000000000u) return false;
 
-    // scene extent (finite triangles only; a triangle with a non-finite coordinate can never be
-    // hit by the triangle test, so it is simply left out of the tree)
-    std::vector<Box> tri_box(n_tris);
+    std::vector<Box> tri_box;
+    std::vector<uint32_t> order = padded_tri_boxes(verts, n_tris, tri_box);
+    if (order.empty()) return true;
     std::vector<float> centroid(n_tris * 3);
-    std::vector<uint32_t> order; order.reserve(n_tris);
-    float scene_ext = 0.0f;
-    {
-        Box sb; sb.reset();
-        for (size_t t = 0; t < n_tris; ++t) {
-            const float *v = verts + t * 9;
-            bool fin = true;
-            for (int k = 0; k < 9; ++k) fin = fin && std::isfinite(v[k]);
-            if (!fin) continue;
-            Box b; b.reset();
-            for (int k = 0; k < 3; ++k)
-                for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], v[k * 3 + a]); b.hi[a] = std::max(b.hi[a], v[k * 3 + a]); }
-            tri_box[t] = b; sb.grow(b);
-            order.push_back((uint32_t)t);
-        }
-        if (order.empty()) return true;
-        for (int a = 0; a < 3; ++a) scene_ext = std::max(scene_ext, sb.hi[a] - sb.lo[a]);
-    }
-    // Pad every triangle box so that box culling can never contradict the triangle test: the
-    // test's edge functions are exact only up to a few ulps of the coordinate magnitude.
-    for (uint32_t t : order) {
-        Box &b = tri_box[t];
-        for (int a = 0; a < 3; ++a) {
-            float m = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
-            float pad = 2e-5f * m + 1e-6f * scene_ext + 1e-30f;
-            b.lo[a] -= pad; b.hi[a] += pad;
-            centroid[(size_t)t * 3 + a] = 0.5f * b.lo[a] + 0.5f * b.hi[a];
-        }
-    }
+    for (uint32_t t : order)
+        for (int a = 0; a < 3; ++a) centroid[(size_t)t * 3 + a] = 0.5f * tri_box[t].lo[a] + 0.5f * tri_box[t].hi[a];
 
     Builder2 b2;
     b2.tri_box = tri_box.data(); b2.centroid = centroid.data();
@@ -288,16 +323,7 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
         }
 
         Bvh8Node nd; memset(&nd, 0, sizeof nd);
-        for (int a = 0; a < 3; ++a) {
-            nd.p[a] = src.box.lo[a];
-            float ext = src.box.hi[a] - src.box.lo[a];
-            int e; float m = std::frexp(ext / 255.0f, &e);   // ext/255 = m * 2^e, m in [0.5,1)
-            (void)m;
-            int be = e + 127;                                // step = 2^e >= ext/255
-            be = std::min(254, std::max(1, be));
-            while (be < 254 && !(nd.p[a] + step_of((uint8_t)be) * 255.0f >= src.box.hi[a])) ++be;
-            nd.e[a] = (uint8_t)be;
-        }
+        set_node_frame(nd, src.box);
         nd.child_base = (uint32_t)out.nodes.size();
         nd.tri_base = (uint32_t)out.tri_order.size();
         uint32_t tri_off = 0, n_inner = 0;
@@ -305,16 +331,7 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
             int c = slot_child[s];
             if (c < 0) continue;
             const Node2 &ch = b2.nodes[kids[c]];
-            for (int a = 0; a < 3; ++a) {
-                float st = step_of(nd.e[a]);
-                int lo = (int)std::floor(((double)ch.box.lo[a] - (double)nd.p[a]) / (double)st);
-                int hi = (int)std::ceil(((double)ch.box.hi[a] - (double)nd.p[a]) / (double)st);
-                lo = std::min(255, std::max(0, lo)); hi = std::min(255, std::max(0, hi));
-                // the decoded planes (fp32: p + q*step) must enclose the child box
-                while (lo > 0 && nd.p[a] + (float)lo * st > ch.box.lo[a]) --lo;
-                while (hi < 255 && nd.p[a] + (float)hi * st < ch.box.hi[a]) ++hi;
-                nd.qlo[a][s] = (uint8_t)lo; nd.qhi[a][s] = (uint8_t)hi;
-            }
+            set_child_planes(nd, s, ch.box);
             if (!dp[kids[c]].leaf) {
                 nd.imask |= (uint8_t)(1u << s);
                 nd.meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
@@ -334,6 +351,53 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
         out.nodes.resize(out.nodes.size() + n_inner);
         out.nodes[qi] = nd;
     }
+    return true;
+}
+
+// Refit: same topology, new triangle positions (instances moved).  Children have larger indices than their
+// parents, so one backward sweep recomputes every node's box from its leaf triangles / inner children and
+// re-quantises the child planes.  `sah` = sum of the node half-areas relative to the root's: the caller
+// compares it with the value right after a build to decide when a moved scene deserves a full rebuild.
+bool refit_bvh8(Bvh8 &bvh, const float *verts, size_t n_tris, double *sah)
+{
+    if (sah) *sah = 0.0;
+    if (bvh.nodes.empty()) return true;
+    std::vector<Box> tri_box;
+    std::vector<uint32_t> finite = padded_tri_boxes(verts, n_tris, tri_box);
+    if (finite.size() != bvh.tri_order.size()) return false;      // a triangle became (non-)finite: rebuild
+    std::vector<Box> node_box(bvh.nodes.size());
+    double area_sum = 0.0;
+    for (size_t i = bvh.nodes.size(); i-- > 0;) {
+        Bvh8Node &nd = bvh.nodes[i];
+        Box child[8]; bool used[8];
+        Box nb; nb.reset();
+        for (int s = 0; s < 8; ++s) {
+            used[s] = nd.meta[s] != 0;
+            if (!used[s]) continue;
+            Box cb; cb.reset();
+            if ((nd.imask >> s) & 1u) {
+                uint32_t rel = (uint32_t)__builtin_popcount(nd.imask & ((1u << s) - 1u));
+                cb = node_box[nd.child_base + rel];
+            } else {
+                uint32_t off = nd.meta[s] & 31u, cnt = (uint32_t)__builtin_popcount((uint32_t)nd.meta[s] >> 5);
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    uint32_t t = bvh.tri_order[nd.tri_base + off + k];
+                    if (!(tri_box[t].lo[0] <= tri_box[t].hi[0])) return false;   // that triangle is no longer finite
+                    cb.grow(tri_box[t]);
+                }
+            }
+            child[s] = cb; nb.grow(cb);
+        }
+        node_box[i] = nb;
+        set_node_frame(nd, nb);
+        for (int s = 0; s < 8; ++s) {
+            if (used[s]) set_child_planes(nd, s, child[s]);
+            else for (int a = 0; a < 3; ++a) { nd.qlo[a][s] = 0; nd.qhi[a][s] = 0; }
+        }
+        area_sum += (double)nb.half_area();
+    }
+    double root = (double)node_box[0].half_area();
+    if (sah) *sah = root > 0.0 ? area_sum / root : 0.0;
     return true;
 }
 

@@ -70,6 +70,10 @@ struct ptx_context {
     LitMaterial *d_lit_materials = nullptr;       // lit integrator
     LightRec *d_lights = nullptr; float *d_light_cdf = nullptr; uint32_t n_lights = 0;
     uint32_t built_options = 0;                   // scene options the current device scene was built with
+    Bvh8 bvh;                                     // host copy of the acceleration structure (refit on instance motion)
+    std::vector<ptx_instance> built_instances;    // the list it was built / last refitted for
+    double built_sah = 0.0;                       // refit_bvh8's cost figure right after the build
+    uint64_t n_builds = 0, n_refits = 0;
     uint32_t bvh_depth = 0;
     bool scene_ready = false;
     bool textures_dirty = true;
@@ -401,7 +405,17 @@ int ptx_create_geometry(ptx_context *c, uint64_t first_vertex, uint64_t n_vertic
     return PTX_OK;
 }
 
-int ptx_set_instances(ptx_context *c, const ptx_instance *inst, uint32_t n)
+static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t n, bool try_refit);
+
+int ptx_set_instances(ptx_context *c, const ptx_instance *inst, uint32_t n) { return set_instances_impl(c, inst, n, false); }
+int ptx_update_instances(ptx_context *c, const ptx_instance *inst, uint32_t n) { return set_instances_impl(c, inst, n, true); }
+
+}  // extern "C"
+
+// A moved scene keeps its tree while the refitted tree's cost figure stays below this multiple of the built tree's.
+static constexpr double kRefitSahLimit = 1.6;
+
+static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t n, bool try_refit)
 {
     if (!c) return PTX_ERR_INVALID;
     if (!inst && n) return fail(c, PTX_ERR_INVALID, "ptx_set_instances: NULL argument");
@@ -444,10 +458,29 @@ int ptx_set_instances(ptx_context *c, const ptx_instance *inst, uint32_t n)
             }
         }
     }
-    Bvh8 bvh;
-    int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (!build_bvh8(wv.data(), n_tris, bvh, threads)) return fail(c, PTX_ERR_INVALID, "ptx_set_instances: BVH build failed");
-    if (bvh.depth > kMaxBvhDepth) return fail(c, PTX_ERR_CAPACITY, "ptx_set_instances: BVH deeper than the traversal stack");
+    // Same entities, new transforms (the reference rebuilds its TLAS every frame, renderer.rs:961, and wants not
+    // to: todo.md:3): keep the tree and refit its boxes, unless the moved scene has made it too loose.
+    bool refitted = false;
+    if (try_refit && c->scene_ready && c->built_instances.size() == n && c->built_options == c->scene_options) {
+        bool same = true;
+        for (uint32_t i = 0; i < n && same; ++i)
+            same = inst[i].geometry == c->built_instances[i].geometry && memcmp(&inst[i].off, &c->built_instances[i].off, sizeof(ptx_offsets)) == 0;
+        double sah = 0.0;
+        if (same && refit_bvh8(c->bvh, wv.data(), n_tris, &sah) && sah <= c->built_sah * kRefitSahLimit) refitted = true;
+    }
+    Bvh8 &bvh = c->bvh;
+    if (!refitted) {
+        int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        c->scene_ready = false;
+        if (!build_bvh8(wv.data(), n_tris, bvh, threads)) return fail(c, PTX_ERR_INVALID, "ptx_set_instances: BVH build failed");
+        if (bvh.depth > kMaxBvhDepth) return fail(c, PTX_ERR_CAPACITY, "ptx_set_instances: BVH deeper than the traversal stack");
+        Bvh8 probe = bvh;                     // the cost figure of the fresh tree, by the same routine that refits
+        if (!refit_bvh8(probe, wv.data(), n_tris, &c->built_sah)) c->built_sah = 0.0;
+        c->n_builds++;
+    } else {
+        c->n_refits++;
+    }
+    c->built_instances.assign(inst, inst + n);
 
     const bool world_normals = (c->scene_options & PTX_SCENE_WORLD_NORMALS) != 0;
     std::vector<float> cof((size_t)n * 9);
@@ -569,6 +602,8 @@ int ptx_set_instances(ptx_context *c, const ptx_instance *inst, uint32_t n)
     c->scene_ready = true;
     return PTX_OK;
 }
+
+extern "C" {
 
 int ptx_resize(ptx_context *c, uint32_t w, uint32_t h)
 {
@@ -787,6 +822,7 @@ int ptx_get_stats(ptx_context *c, ptx_stats *s)
     s->bvh_bytes = (uint64_t)c->n_nodes * sizeof(Bvh8Node) + c->n_tris * (sizeof(TriRec) + sizeof(ShadeRec));
     s->bvh_depth = c->bvh_depth;
     s->shadow_rays = t[11]; s->lights = c->n_lights;
+    s->bvh_builds = c->n_builds; s->bvh_refits = c->n_refits;
     return PTX_OK;
 }
 

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libpt_host.so")
 EXPORTS = ["pth_last_error", "pth_renderer_create", "pth_renderer_destroy", "pth_renderer_context", "pth_import_gltf",
            "pth_set_camera", "pth_set_seed", "pth_set_params", "pth_set_accumulation_limit", "pth_accumulated_count",
            "pth_resize", "pth_record_commands", "pth_record_commands_batch", "pth_save_image", "pth_scene_counts",
-           "pth_scene_copy", "pth_camera_matrices", "pth_decode_image", "pth_encode_png_rgb8", "pth_set_ref_quirks"]
+           "pth_scene_copy", "pth_camera_matrices", "pth_decode_image", "pth_encode_png_rgb8", "pth_set_ref_quirks", "pth_set_entity_transform"]
 _lib = None
 
 
@@ -38,6 +38,7 @@ def load():
     L.pth_renderer_context.restype = vp
     L.pth_import_gltf.argtypes = [vp, C.c_char_p, C.c_float, C.c_float, C.c_float]
     L.pth_set_ref_quirks.argtypes = [vp, C.c_int]
+    L.pth_set_entity_transform.argtypes = [vp, C.c_uint64, fp, fp, fp]
     L.pth_set_camera.argtypes = [vp, fp, fp, C.c_float, C.c_float, C.c_float]
     L.pth_set_seed.argtypes = [vp, C.c_uint32, C.c_int]
     L.pth_set_params.argtypes = [vp, C.POINTER(capi.RenderParams)]
@@ -131,6 +132,12 @@ class Renderer:
         """False = SURVEY 8f.2's --no-ref-quirks: world-space normals, texel x baseColorFactor, child nodes,
         sampler wrap modes.  Call before import_gltf."""
         _check(self._L.pth_set_ref_quirks(self.handle, int(bool(on))))
+
+    def set_entity_transform(self, index, pos, quat=(0, 0, 0, 1), scale=(1, 1, 1)):
+        """Moves an entity (the reference's UI edits Transform components in place); the acceleration
+        structure is refitted, not rebuilt, on the next frame."""
+        _check(self._L.pth_set_entity_transform(self.handle, index, _fp(np.asarray(pos, np.float32)),
+                                                _fp(np.asarray(quat, np.float32)), _fp(np.asarray(scale, np.float32))))
 
     def set_camera(self, pos, quat=(0, 0, 0, 1), fov_y=np.deg2rad(np.float32(70.0)), z_near=0.1, z_far=1000.0):
         _check(self._L.pth_set_camera(self.handle, _fp(np.asarray(pos, np.float32)), _fp(np.asarray(quat, np.float32)),

@@ -3,6 +3,7 @@
 // pth_last_error() holds the message of the last failure on the calling thread.
 #include <cstring>
 #include <exception>
+#include <stdexcept>
 #include <string>
 
 #include "pth_image.h"
@@ -37,6 +38,18 @@ int pth_import_gltf(void *r, const char *path, float ox, float oy, float oz)
 }
 
 int pth_set_ref_quirks(void *r, int on) { return guard([&] { ((Renderer *)r)->set_ref_quirks(on != 0); }); }
+
+// moves entity `index` (the UI's transform editor, config_window.rs); the next frame is scene-dirty
+int pth_set_entity_transform(void *r, uint64_t index, const float pos[3], const float quat_xyzw[4], const float scale[3])
+{
+    return guard([&] {
+        std::vector<Entity> &w = ((Renderer *)r)->scene.world_mut();
+        if (index >= w.size()) throw std::runtime_error("entity index out of range");
+        w[index].transform.position = Vec3(pos[0], pos[1], pos[2]);
+        w[index].transform.rotation = Quat{quat_xyzw[0], quat_xyzw[1], quat_xyzw[2], quat_xyzw[3]};
+        w[index].transform.scale = Vec3(scale[0], scale[1], scale[2]);
+    });
+}
 
 int pth_set_camera(void *r, const float pos[3], const float quat_xyzw[4], float fov_y, float z_near, float z_far)
 {

@@ -86,7 +86,8 @@ void Renderer::sync_instances()
         inst[i].off.index_offset = (uint32_t)e.geometry.shared_index_buffer_offset;
         inst[i].off.index_count = (uint32_t)e.geometry.shared_index_buffer_count;
     }
-    if (ptx_set_instances(ctx_, inst.data(), (uint32_t)inst.size())) ptx_throw(ctx_, "build_top_level_acceleration_structure");
+    // ptx_update_instances refits when the list only moved and rebuilds otherwise
+    if (ptx_update_instances(ctx_, inst.data(), (uint32_t)inst.size())) ptx_throw(ctx_, "build_top_level_acceleration_structure");
 }
 
 uint32_t Renderer::next_seed()

@@ -38,6 +38,19 @@ void *bvhcheck_create(const float *verts, const uint32_t *ids, uint64_t n_tris, 
     }
     return c;
 }
+// moved triangles, same topology: refit the tree in place.  Returns 1 on success and the cost figure in *sah.
+int bvhcheck_refit(void *h, const float *verts, const uint32_t *ids, uint64_t n_tris, double *sah)
+{
+    Check *c = (Check *)h;
+    if (!refit_bvh8(c->bvh, verts, n_tris, sah)) return 0;
+    for (size_t i = 0; i < c->tris.size(); ++i) {
+        uint32_t t = c->bvh.tri_order[i];
+        TriRec &r = c->tris[i];
+        for (int a = 0; a < 3; ++a) { r.v0[a] = verts[t * 9 + a]; r.v1[a] = verts[t * 9 + 3 + a]; r.v2[a] = verts[t * 9 + 6 + a]; }
+        r.instance = ids[t * 2]; r.prim = ids[t * 2 + 1];
+    }
+    return 1;
+}
 void bvhcheck_destroy(void *h) { delete (Check *)h; }
 void bvhcheck_info(void *h, uint64_t *n_nodes, uint64_t *n_tris, uint32_t *depth)
 {

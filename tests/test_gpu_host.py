@@ -127,3 +127,46 @@ def test_headless_cli_matches_the_host_renderer(tmp_path):
     # an existing output is not overwritten (renderer.rs:752-754)
     r = subprocess.run([cli, gltf, "--res", "8x8", "--spp", "1", "--out", out], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "exists" in r.stderr.lower()
+
+
+def test_entity_motion_refits_and_matches_oracle(oracle):
+    """todo.md:3 / SURVEY 8f.4: moving an entity refits the acceleration structure (no rebuild) and the image
+    equals the oracle's render of the moved scene bit for bit; a changed entity list rebuilds."""
+    import os
+    from helpers import ASSETS, SEED, assert_images_bit_equal, cornell
+    from path_tracer_amd import capi, host
+    r = host.Renderer(96, 96, 0)
+    r.import_gltf(os.path.join(ASSETS, "cornell", "cornell.gltf"))
+    fov = np.deg2rad(np.float32(40.0))
+    r.set_camera([0.0, 1.0, 3.9], host.yaw_quat(0.0), fov, 0.1, 1000.0)
+    r.set_seed(SEED, fixed=True)
+    r.set_params(capi.default_params(max_depth=8))
+    r.record_commands(); r.record_commands()
+    st = r.stats()
+    assert st["bvh_builds"] == 1 and st["bvh_refits"] == 0
+    ing = cornell()
+    geom, (p, q, s), mat = ing.entities[6]
+    new_p = p + np.float32([0.3, 0.25, 0.35]); new_s = s * np.float32([1.0, 1.3, 1.0])
+    ing.entities[6] = (geom, (new_p, q, new_s), mat)
+    r.set_entity_transform(6, new_p, q, new_s)
+    r.record_commands()          # scene-dirty frame: refit, accumulated_count restarts
+    r.record_commands_batch(3)
+    st = r.stats()
+    assert st["bvh_builds"] == 1 and st["bvh_refits"] == 1
+    got = {k: r.read_image(v) for k, v in (("albedo", capi.IMAGE_ALBEDO), ("normal", capi.IMAGE_NORMAL),
+                                           ("depth", capi.IMAGE_DEPTH), ("ids", capi.IMAGE_PRIMARY_ID))}
+    cam = oracle.camera_matrices([0.0, 1.0, 3.9], oracle.yaw_quat(0.0), fov, 1.0, 0.1, 1000.0)
+    want = oracle.scene_from_ingest(ing).render(cam, 96, 96, 3, SEED, params=oracle.default_params(max_depth=8))
+    assert_images_bit_equal(got, want, "cornell after moving the short box (refit)")
+    # a far move loosens the tree beyond the limit -> rebuild; same image rule
+    far_p = new_p + np.float32([0.0, 40.0, 0.0])
+    r.set_entity_transform(6, far_p, q, new_s)
+    r.record_commands()
+    st = r.stats()
+    assert st["bvh_builds"] + st["bvh_refits"] == 3
+    # importing another scene changes the entity list -> rebuild
+    r.import_gltf(os.path.join(ASSETS, "cornell", "cornell.gltf"), (3.0, 0.0, 0.0))
+    r.record_commands()
+    st2 = r.stats()
+    assert st2["bvh_builds"] == st["bvh_builds"] + 1
+    r.close()

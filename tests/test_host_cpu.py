@@ -88,6 +88,7 @@ def bvh_check():
     L.bvhcheck_create.restype = C.c_void_p
     L.bvhcheck_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
     L.bvhcheck_destroy.argtypes = [C.c_void_p]
+    L.bvhcheck_refit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
     L.bvhcheck_info.argtypes = [C.c_void_p] * 4
     L.bvhcheck_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_float] + [C.c_void_p] * 5
     return L
@@ -142,6 +143,54 @@ def test_bvh8_traversal_equals_oracle_brute_force(oracle, bvh_check, scene, cent
             assert (np.float32(r[0]), np.float32(r[1]), np.float32(r[2]), r[3], r[4]) == (tuv[i, 0], tuv[i, 1], tuv[i, 2], hid[i, 0], hid[i, 1])
     assert hits > n // 10
     bvh_check.bvhcheck_destroy(h)
+
+
+def test_bvh8_refit_after_instance_motion(oracle, bvh_check):
+    """ptx_update_instances' refit (todo.md:3): the tree built for the Cornell box still answers closest-hit
+    queries exactly after the two boxes have been moved, rotated and scaled -- checked against the oracle's
+    brute force on the moved scene -- and its cost figure grows with the motion."""
+    ing = cornell()
+    v0, ids = _world_tris(ing, oracle)
+    h = bvh_check.bvhcheck_create(v0.ctypes.data, ids.ctypes.data, len(v0), 2)
+    sah0 = C.c_double()
+    assert bvh_check.bvhcheck_refit(h, v0.ctypes.data, ids.ctypes.data, len(v0), C.byref(sah0)) == 1
+    # move entities 6 and 7 (short and tall box)
+    for e, (pos, yaw, sc) in ((6, ((0.35, 0.3, 0.4), 40.0, (1.0, 1.0, 1.0))), (7, ((-0.3, 0.0, -0.2), -25.0, (0.8, 1.2, 0.8)))):
+        geom, (p, q, s), mat = ing.entities[e]
+        ing.entities[e] = (geom, (p + np.float32(pos), _quat_mul(oracle.yaw_quat(yaw), q), s * np.float32(sc)), mat)
+    v1, ids1 = _world_tris(ing, oracle)
+    assert np.array_equal(ids, ids1) and not np.array_equal(v0, v1)
+    sah1 = C.c_double()
+    assert bvh_check.bvhcheck_refit(h, v1.ctypes.data, ids1.ctypes.data, len(v1), C.byref(sah1)) == 1
+    assert sah1.value != sah0.value
+    moved = oracle.scene_from_ingest(ing)
+    n = 4000
+    rng = np.random.default_rng(3)
+    o = (rng.normal(size=(n, 3)) + (0, 1, 0)).astype(np.float32)
+    d = ((rng.normal(size=(n, 3)) * 0.5 + (0, 1, 0)).astype(np.float32) - o).astype(np.float32)
+    rays = np.ascontiguousarray(np.concatenate([o, d], 1), np.float32)
+    tuv = np.zeros((n, 3), np.float32); hid = np.zeros((n, 2), np.uint32)
+    bvh_check.bvhcheck_trace(h, rays.ctypes.data, n, 1e-3, 1e4, tuv.ctypes.data, hid.ctypes.data, None, None, None)
+    hits = 0
+    for i in range(n):
+        r = moved.trace(o[i], d[i], flags=1)
+        if r is None:
+            assert hid[i, 0] == 0xFFFFFFFF
+        else:
+            hits += 1
+            assert (np.float32(r[0]), r[3], r[4]) == (tuv[i, 0], hid[i, 0], hid[i, 1])
+    assert hits > n // 10
+    # a triangle that stops being finite cannot be refitted (the caller rebuilds)
+    bad = v1.copy(); bad[5, 0] = np.nan
+    assert bvh_check.bvhcheck_refit(h, bad.ctypes.data, ids1.ctypes.data, len(bad), C.byref(sah1)) == 0
+    bvh_check.bvhcheck_destroy(h)
+
+
+def _quat_mul(a, b):
+    ax, ay, az, aw = (np.float32(x) for x in a)
+    bx, by, bz, bw = (np.float32(x) for x in b)
+    return np.float32([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                       aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
 
 
 def test_bvh8_edge_cases(bvh_check):
