@@ -54,6 +54,9 @@ def main():
                     help="reference: the reference's rchit/rmiss shading (the headline number); lit: the build's "
                          "extension with emissive triangles + next-event estimation + GGX/glass BSDFs (SURVEY 8f.3)")
     ap.add_argument("--cpu-baseline-spp", type=int, default=2, help="0 disables the CPU leg")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="rehearsal of the N > 1 path on a box with ONE GPU: every rank renders on device 0 and the "
+                         "accumulation reduce goes through host memory over gloo (RCCL refuses two ranks on one device)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
     args = ap.parse_args()
 
@@ -67,13 +70,18 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_gloo:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from path_tracer_amd import capi, host, standins
     wl = WORKLOADS[args.workload]
     assets = os.path.join(ROOT, "assets")
-    if local_rank == 0:
+    if rank == 0 or (local_rank == 0 and not args.rehearse_gloo):
         standins.ensure_standins(assets)
     if dist is not None:
         dist.barrier()
@@ -110,7 +118,8 @@ def main():
         red = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:%d" % local_rank)
         # untimed warm-up of the one collective the job uses: RCCL sets up its channels for this message size on
         # first use (the timed region then measures the reduce itself, 33 MB at 1080p)
-        dist.reduce(red, dst=0, op=dist.ReduceOp.SUM)
+        if not args.rehearse_gloo:
+            dist.reduce(red, dst=0, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
 
     # ---------------- timed region: exactly K steps + the one accumulation reduce ----------------
@@ -125,7 +134,14 @@ def main():
         r.record_commands_batch(spp)
     if dist is not None:
         ctx.export_albedo_device(red.data_ptr(), red.numel() * 4, 1.0)
-        combined = combine_accumulation(red, dist, world, root=0)
+        if args.rehearse_gloo:
+            host_img = red.cpu()
+            combined = combine_accumulation(host_img, dist, world, root=0)
+            if combined is not None:
+                red.copy_(combined)
+                combined = red
+        else:
+            combined = combine_accumulation(red, dist, world, root=0)
         if combined is not None:
             torch.cuda.synchronize()
             ctx.import_albedo_device(combined.data_ptr(), combined.numel() * 4, 1.0)
@@ -138,10 +154,11 @@ def main():
     ctx.set_profiling(0)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
+        stat_dev = "cpu" if args.rehearse_gloo else "cuda:%d" % local_rank
+        t = torch.tensor([elapsed], dtype=torch.float64, device=stat_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([st["samples"], st["rays"]], dtype=torch.float64, device="cuda:%d" % local_rank)
+        cnt = torch.tensor([st["samples"], st["rays"]], dtype=torch.float64, device=stat_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         job_samples, job_rays = float(cnt[0].item()), float(cnt[1].item())
     else:
