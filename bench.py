@@ -175,6 +175,12 @@ def main():
         nodes_per_ray = ist["nodes_fetched"] / max(1, ist["rays"])
         tris_per_ray = ist["tris_tested"] / max(1, ist["rays"])
         bytes_per_ray = nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES + RAY_BYTES + HIT_BYTES
+        # SIMD divergence of the traversal kernel, counted live by its instrumented build (same workload): lanes that
+        # take part in a node block / triangle block out of the wave's 64
+        ws = ist["wave_sched"]          # wave iterations, node blocks, lanes in them, triangle blocks, lanes in them, refills
+        divergence = dict(node_block_lanes=round(ws[2] / max(1, ws[1]) / 64.0, 4), tri_block_lanes=round(ws[4] / max(1, ws[3]) / 64.0, 4),
+                          node_blocks_per_iteration=round(ws[1] / max(1, ws[0]), 4), tri_blocks_per_iteration=round(ws[3] / max(1, ws[0]), 4),
+                          source="instrumented k_extend<stats> on one untimed step of the same workload")
         launches = max(1, st["extend_launches"])
         rays_per_launch = st["rays"] / launches
         avg_launch_s = st["extend_ms"] * 1e-3 / launches
@@ -205,7 +211,7 @@ def main():
                         tris_per_ray=round(tris_per_ray, 2), rays_per_launch=round(rays_per_launch, 1),
                         avg_launch_ms=round(avg_launch_s * 1e3, 4), launches=int(launches),
                         extend_ms=round(st["extend_ms"], 2), shade_ms=round(st["shade_ms"], 2),
-                        valu=valu,
+                        valu=valu, divergence=divergence,
                         note="frac > 1 is not an error: the algorithmic bytes count every node and triangle a ray touches, and the "
                              "scene + BVH (48 MB) are served from L2 / Infinity Cache, so measured HBM traffic (`traffic`) is far below "
                              "them and HBM does not bound this kernel.  VALU issue does: `valu.busy` = fraction of SIMD issue slots "
