@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import ASSETS, SEED, assert_images_bit_equal, copy_struct, gpu_render, ingest, upload
+from helpers import ASSETS, SEED, assert_images_bit_equal, copy_struct, cornell, gpu_render, ingest, upload
 
 pytestmark = pytest.mark.gpu
 
@@ -133,3 +133,57 @@ def test_error_paths(oracle, gpu_ctx_factory):
     ctx.render(u, cam)
     img = ctx.read_image(capi.IMAGE_ALBEDO)
     assert np.all(ctx.read_image(capi.IMAGE_PRIMARY_ID) == 0xFFFFFFFF) and img[0, 0, 2] > 0.5
+
+
+def test_frames_in_flight_equal_serial_frames(oracle, monkeypatch):
+    """consecutive ptx_render calls overlap on two streams (two path sets, event-chained resolves).
+    The images must equal those of strictly serial frames (PTX_FRAMES_IN_FLIGHT=1) bit for bit, through camera
+    moves with and without an accumulation restart, batches after single frames, and a resize."""
+    from helpers import copy_struct
+    from path_tracer_amd import capi
+    ing = cornell()
+
+    def run(frames_in_flight):
+        monkeypatch.setenv("PTX_FRAMES_IN_FLIGHT", str(frames_in_flight))
+        ctx = capi.Context(0)
+        upload(ctx, ing, oracle)
+        ctx.resize(160, 120)
+        cams = [copy_struct(capi.Camera, oracle.camera_matrices(p, oracle.yaw_quat(y), np.deg2rad(np.float32(40)), 160 / 120, 0.1, 1000.0))
+                for p, y in (([0, 1.0, 3.9], 0.0), ([0.4, 1.1, 3.5], 8.0), ([-0.5, 0.8, 3.0], -12.0))]
+        p = capi.default_params(max_depth=8)
+        snaps = []
+
+        def frame(cam, acc, n=1):
+            u = capi.Uniforms(1, SEED, acc, 0.1, 100.0, (0, 0, 0))
+            if n == 1:
+                ctx.render(u, cam, p)
+            else:
+                ctx.render_batch(u, cam, n, p)
+        for acc in range(5):
+            frame(cams[0], acc)                     # clean accumulating frames: these overlap
+        frame(cams[1], 0)                           # camera moved, accumulation restarts: waits for everything before it
+        frame(cams[1], 1); frame(cams[1], 2)
+        snaps.append({k: ctx.read_image(v) for k, v in (("albedo", capi.IMAGE_ALBEDO), ("normal", capi.IMAGE_NORMAL),
+                                                        ("depth", capi.IMAGE_DEPTH), ("ids", capi.IMAGE_PRIMARY_ID))})
+        frame(cams[2], 3)                           # a caller that moves the camera WITHOUT restarting: still ordered
+        frame(cams[2], 4, n=3)
+        frame(cams[2], 7)
+        snaps.append({k: ctx.read_image(v) for k, v in (("albedo", capi.IMAGE_ALBEDO), ("normal", capi.IMAGE_NORMAL),
+                                                        ("depth", capi.IMAGE_DEPTH), ("ids", capi.IMAGE_PRIMARY_ID))})
+        ctx.resize(96, 64)
+        for acc in range(4):
+            frame(cams[0], acc)
+        snaps.append({k: ctx.read_image(v) for k, v in (("albedo", capi.IMAGE_ALBEDO), ("normal", capi.IMAGE_NORMAL),
+                                                        ("depth", capi.IMAGE_DEPTH), ("ids", capi.IMAGE_PRIMARY_ID))})
+        ctx.close()
+        return snaps
+
+    serial, two, four = run(1), run(2), run(4)
+    for i, (a, b, c) in enumerate(zip(serial, two, four)):
+        assert_images_bit_equal(b, a, "2 frames in flight vs serial, snapshot %d" % i)
+        assert_images_bit_equal(c, a, "4 frames in flight vs serial, snapshot %d" % i)
+    # and the serial schedule equals the oracle for the first camera sequence's restart
+    sc = oracle.scene_from_ingest(ing)
+    cam1 = oracle.camera_matrices([0.4, 1.1, 3.5], oracle.yaw_quat(8.0), np.deg2rad(np.float32(40)), 160 / 120, 0.1, 1000.0)
+    want = sc.render(cam1, 160, 120, 3, SEED, params=oracle.default_params(max_depth=8))
+    assert_images_bit_equal(serial[0], want, "serial frames vs oracle")
