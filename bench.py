@@ -200,7 +200,7 @@ def main():
             try:
                 d = json.load(open(vj))
                 if d.get("workload") == args.workload:
-                    k = d["kernels"]["k_extend<false>"]
+                    k = d["kernels"].get("k_extend<false, false>") or d["kernels"]["k_extend<false>"]
                     valu = dict(busy=round(k["valu_busy"], 4), lane_util=round(k["lane_util"], 4), residency=round(k["residency"], 4),
                                 source="profiles/valu.json (rocprofv3 --pmc, same workload and launch size)")
             except Exception:

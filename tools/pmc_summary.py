@@ -5,7 +5,7 @@ out = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for f in glob.glob(root + "/pmc_*/**/*_counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        m = re.search(r"(k_\w+(<\w+>)?)", row["Kernel_Name"]); k = m.group(1) if m else row["Kernel_Name"].split("(")[0]
+        m = re.search(r"(k_\w+(<[\w, ]+>)?)", row["Kernel_Name"]); k = m.group(1) if m else row["Kernel_Name"].split("(")[0]
         out[k][row["Counter_Name"]] += float(row["Counter_Value"])
         disp[(k, row["Counter_Name"])].add(row["Dispatch_Id"])
 res = {}

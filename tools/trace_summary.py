@@ -6,7 +6,7 @@ trace, steps, bounces = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 rows = list(csv.DictReader(open(trace)))
 per = {}
 for r in rows:
-    m = re.search(r"(k_\w+(<\w+>)?|__amd\w+)", r["Kernel_Name"])
+    m = re.search(r"(k_\w+(<[\w, ]+>)?|__amd\w+)", r["Kernel_Name"])
     k = m.group(1) if m else r["Kernel_Name"]
     per.setdefault(k, []).append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6,
                                   int(r["VGPR_Count"]), int(r["LDS_Block_Size"]), int(r["Scratch_Size"])))
@@ -16,7 +16,7 @@ for k, v in per.items():
     d = [x[1] for x in v]
     out["kernels"][k] = {"calls": len(d), "total_ms": round(sum(d), 3), "avg_ms": round(sum(d) / len(d), 4),
                          "vgprs": v[0][2], "lds_bytes": v[0][3], "scratch_bytes": v[0][4]}
-ext = [x[1] for x in per.get("k_extend<false>", [])]
+ext = [x[1] for x in per.get("k_extend<false, false>", [])]
 n = steps * bounces
 if len(ext) >= n:
     timed = ext[-n:]
