@@ -70,6 +70,8 @@ struct ptx_context {
     LitMaterial *d_lit_materials = nullptr;       // lit integrator
     LightRec *d_lights = nullptr; float *d_light_cdf = nullptr; uint32_t n_lights = 0;
     uint32_t built_options = 0;                   // scene options the current device scene was built with
+    void *staging = nullptr; uint64_t staging_bytes = 0;   // pinned host staging for scene uploads
+    uint64_t cap_nodes = 0, cap_tris = 0;         // element capacities of d_nodes / d_tris + d_shade (reused across rebuilds)
     Bvh8 bvh;                                     // host copy of the acceleration structure (refit on instance motion)
     std::vector<ptx_instance> built_instances;    // the list it was built / last refitted for
     double built_sah = 0.0;                       // refit_bvh8's cost figure right after the build
@@ -149,6 +151,30 @@ int ensure_paths(ptx_context *c, PathSet &ps, uint64_t n, bool shadow_queue)
         ps.capacity = n;
     }
     if (shadow_queue && !ps.d_rays[2]) HIP_TRY(c, hipMalloc(&ps.d_rays[2], ps.capacity * kRayBytes));
+    return PTX_OK;
+}
+
+// Host loops over triangles (flatten, pack) are embarrassingly parallel: static slices over up to 16 threads.
+template <class F> void parallel_for(uint64_t n, F &&fn)
+{
+    unsigned nt = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (n < 65536 || nt == 1) { fn((uint64_t)0, n); return; }
+    std::vector<std::thread> th;
+    uint64_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        uint64_t lo = std::min<uint64_t>(n, t * per), hi = std::min<uint64_t>(n, lo + per);
+        if (lo < hi) th.emplace_back([=, &fn] { fn(lo, hi); });
+    }
+    for (std::thread &t : th) t.join();
+}
+
+// page-locked staging buffer of the packed scene (TriRec + ShadeRec): uploads run at the link's rate
+int ensure_staging(ptx_context *c, uint64_t bytes)
+{
+    if (bytes <= c->staging_bytes) return PTX_OK;
+    if (c->staging) { (void)hipHostFree(c->staging); c->staging = nullptr; c->staging_bytes = 0; }
+    HIP_TRY(c, hipHostMalloc(&c->staging, bytes, hipHostMallocDefault));
+    c->staging_bytes = bytes;
     return PTX_OK;
 }
 
@@ -295,6 +321,7 @@ int ptx_destroy(ptx_context *c)
     for (TexDesc &t : c->textures) { void *p = (void *)t.texels; if (p) (void)hipFree(p); }
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_textures); dfree(c->d_lut);
     dfree(c->d_lit_materials); dfree(c->d_lights); dfree(c->d_light_cdf);
+    if (c->staging) (void)hipHostFree(c->staging);
     dfree(c->d_albedo); dfree(c->d_normal); dfree(c->d_depth); dfree(c->d_ids);
     for (int i = 0; i < kMaxSets; ++i) {
         PathSet &ps = c->sets[i];
@@ -446,17 +473,19 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
     {
         uint64_t k = 0;
         for (uint32_t i = 0; i < n; ++i) {
-            const ptx_instance &in = inst[i];
-            const Geometry &g = c->geometries[in.geometry];
-            uint64_t np = g.n_indices / 3;
-            for (uint64_t p = 0; p < np; ++p, ++k) {
-                for (int v = 0; v < 3; ++v) {
-                    const ptx_vertex &vx = c->vertices[g.first_vertex + c->indices[g.first_index + p * 3 + v]];
-                    xform_point(in.xform, vx.position, &wv[k * 9 + v * 3]);
-                }
-                tri_inst[k] = i; tri_prim[k] = (uint32_t)p;
-            }
+            uint64_t np = c->geometries[inst[i].geometry].n_indices / 3;
+            for (uint64_t p = 0; p < np; ++p, ++k) { tri_inst[k] = i; tri_prim[k] = (uint32_t)p; }
         }
+        parallel_for(n_tris, [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t t = lo; t < hi; ++t) {
+                const ptx_instance &in = inst[tri_inst[t]];
+                const Geometry &g = c->geometries[in.geometry];
+                for (int v = 0; v < 3; ++v) {
+                    const ptx_vertex &vx = c->vertices[g.first_vertex + c->indices[g.first_index + (uint64_t)tri_prim[t] * 3 + v]];
+                    xform_point(in.xform, vx.position, &wv[t * 9 + v * 3]);
+                }
+            }
+        });
     }
     // Same entities, new transforms (the reference rebuilds its TLAS every frame, renderer.rs:961, and wants not
     // to: todo.md:3): keep the tree and refit its boxes, unless the moved scene has made it too loose.
@@ -532,9 +561,11 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
     }
 
     uint64_t nt = bvh.tri_order.size();
-    std::vector<TriRec> tris(nt);
-    std::vector<ShadeRec> shade(nt);
-    for (uint64_t k = 0; k < nt; ++k) {
+    if (int r = ensure_staging(c, nt * (sizeof(TriRec) + sizeof(ShadeRec)) + 256)) return r;
+    ShadeRec *shade = reinterpret_cast<ShadeRec *>(c->staging);                 // 128-byte records first (alignment)
+    TriRec *tris = reinterpret_cast<TriRec *>(shade + nt);
+    parallel_for(nt, [&](uint64_t klo, uint64_t khi) {
+    for (uint64_t k = klo; k < khi; ++k) {
         uint32_t t = bvh.tri_order[k];
         const ptx_instance &in = inst[tri_inst[t]];
         const Geometry &g = c->geometries[in.geometry];
@@ -561,23 +592,31 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
         }
         memcpy(sr.uv0, a.uv, 8); memcpy(sr.uv1, b.uv, 8); memcpy(sr.uv2, d.uv, 8);
     }
+    });
 
     if (int r = sync_all(c)) return r;
-    dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade);
     dfree(c->d_lit_materials); dfree(c->d_lights); dfree(c->d_light_cdf);
     c->n_lights = 0;
     c->scene_ready = false;
     c->n_nodes = (uint32_t)bvh.nodes.size(); c->n_tris = nt; c->bvh_depth = bvh.depth;
-    if (c->n_nodes) {
+    // device buffers are kept across rebuilds / refits while they are large enough
+    if (bvh.nodes.size() > c->cap_nodes) {
+        dfree(c->d_nodes); c->cap_nodes = 0;
         HIP_TRY(c, hipMalloc((void **)&c->d_nodes, bvh.nodes.size() * sizeof(Bvh8Node)));
-        HIP_TRY(c, hipMemcpy(c->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(Bvh8Node), hipMemcpyHostToDevice));
+        c->cap_nodes = bvh.nodes.size();
     }
-    if (nt) {
+    if (nt > c->cap_tris) {
+        dfree(c->d_tris); dfree(c->d_shade); c->cap_tris = 0;
         HIP_TRY(c, hipMalloc((void **)&c->d_tris, nt * sizeof(TriRec)));
-        HIP_TRY(c, hipMemcpy(c->d_tris, tris.data(), nt * sizeof(TriRec), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMalloc((void **)&c->d_shade, nt * sizeof(ShadeRec)));
-        HIP_TRY(c, hipMemcpy(c->d_shade, shade.data(), nt * sizeof(ShadeRec), hipMemcpyHostToDevice));
+        c->cap_tris = nt;
     }
+    if (c->n_nodes) HIP_TRY(c, hipMemcpyAsync(c->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(Bvh8Node), hipMemcpyHostToDevice, c->stream));
+    if (nt) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_tris, tris, nt * sizeof(TriRec), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_shade, shade, nt * sizeof(ShadeRec), hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (!lit_materials.empty()) {
         HIP_TRY(c, hipMalloc((void **)&c->d_lit_materials, lit_materials.size() * sizeof(LitMaterial)));
         HIP_TRY(c, hipMemcpy(c->d_lit_materials, lit_materials.data(), lit_materials.size() * sizeof(LitMaterial), hipMemcpyHostToDevice));
