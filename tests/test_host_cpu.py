@@ -261,3 +261,27 @@ def test_headless_cli_builds_and_validates_arguments(tmp_path):
         r = subprocess.run([cli, os.path.join(ASSETS, "cornell/cornell.gltf"), "--res", "8x8", "--spp", "1",
                             "--out", str(tmp_path / "o")], capture_output=True, text=True)
         assert r.returncode == 1 and "ptx-render:" in r.stderr and not (tmp_path / "o.png").exists()
+
+
+def test_native_host_code_under_asan_ubsan(tmp_path):
+    """Host-side sanitizer run (GPU sanitizers are not available on this pool): the PNG / JPEG decoders on whole,
+    truncated and corrupted files, the glTF JSON parser on broken documents, and BVH8 build / refit / traversal on
+    random soups with degenerate, coincident and non-finite triangles, all under -fsanitize=address,undefined."""
+    exe = os.path.join(ROOT, "tests", "_build", "sanitize_main")
+    srcs = [os.path.join(ROOT, "tests", "native", "sanitize_main.cpp"), os.path.join(ROOT, "path_tracer_amd", "csrc", "bvh_build.cpp"),
+            os.path.join(ROOT, "path_tracer_amd", "host", "pth_image.cpp")]
+    deps = srcs + [os.path.join(ROOT, "path_tracer_amd", "csrc", f) for f in ("traverse.h", "bvh8.h", "pt_math.h")] + \
+        [os.path.join(ROOT, "path_tracer_amd", "host", f) for f in ("pth_image.h", "pth_json.h")]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                               "-ffp-contract=off", "-pthread"] + srcs + ["-lz", "-o", exe])
+    # the two smallest real textures of each codec keep the run to a few seconds
+    sponza = os.path.join(ASSETS, "sponza")
+    pngs = sorted((os.path.getsize(os.path.join(sponza, f)), f) for f in os.listdir(sponza) if f.endswith(".png"))
+    jpgs = sorted((os.path.getsize(os.path.join(sponza, f)), f) for f in os.listdir(sponza) if f.endswith(".jpg"))
+    imgs = [os.path.join(sponza, pngs[0][1]), os.path.join(sponza, jpgs[0][1])]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:verify_asan_link_order=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, str(tmp_path / "img.tmp")] + imgs, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "images decoded" in r.stdout
