@@ -217,6 +217,16 @@ def main():
                              "them and HBM does not bound this kernel.  VALU issue does: `valu.busy` = fraction of SIMD issue slots "
                              "spent on VALU instructions (DESIGN.md section 5)")
 
+        # second kernel: k_shade streams the ray queues (HBM) and gathers one 128-byte record per hit (L2 / Infinity Cache).
+        # algorithmic bytes: ray 48 + hit 8 read per ray; ShadeRec 128 (+4 texel) per hit ray; 64 written per surviving
+        # ray; 16 per terminated path (every path terminates once: survivors = rays - samples)
+        shade_bytes = st["rays"] * 56.0 + st["hits"] * 132.0 + (st["rays"] - st["samples"]) * 64.0 + st["samples"] * 16.0
+        shade = dict(bound="hbm", kernel="k_shade", achieved=round(shade_bytes / (st["shade_ms"] * 1e-3) / 1e9, 2) if st["shade_ms"] > 0 else 0.0,
+                     peak=HBM_PEAK_GBS, unit="GB/s", algorithmic_bytes_per_ray=round(shade_bytes / max(1, st["rays"]), 1),
+                     note="HIP-event time of every k_shade launch of the timed region; overlapping launches of the other chunk in flight inflate it slightly")
+        shade["frac"] = round(shade["achieved"] / HBM_PEAK_GBS, 5)
+        roofline["second_kernel"] = shade
+
         cpu = None
         parity = None
         if args.cpu_baseline_spp > 0:

@@ -124,8 +124,10 @@ int main(int argc, char **argv)
             count[g] = spp / gpus + ((uint32_t)g < spp % gpus ? 1u : 0u);
             rs[g]->params.rng_sample_offset = first;
             first += count[g];
-            // the reference's first frame after a change is overwritten by the next (renderer.rs:988-1000):
-            // settle it with one frame, then accumulate the slice
+            // the reference's frames after a change are overwritten: the first is camera-dirty, the second scene-dirty
+            // (the short-circuit at renderer.rs:995 leaves the scene flag set) -- settle both, then accumulate the slice,
+            // so that the image holds exactly count[g] samples
+            rs[g]->record_commands();
             rs[g]->record_commands();
             rs[g]->record_commands_batch(count[g]);
         }

@@ -187,3 +187,35 @@ def test_frames_in_flight_equal_serial_frames(oracle, monkeypatch):
     cam1 = oracle.camera_matrices([0.4, 1.1, 3.5], oracle.yaw_quat(8.0), np.deg2rad(np.float32(40)), 160 / 120, 0.1, 1000.0)
     want = sc.render(cam1, 160, 120, 3, SEED, params=oracle.default_params(max_depth=8))
     assert_images_bit_equal(serial[0], want, "serial frames vs oracle")
+
+
+def test_c5_converged_4096spp_rel_mse(oracle, gpu_ctx_factory, standins_ready):
+    """BASELINE.json: converged images must match the reference's render within rel-MSE <= 1e-3 at 4096 spp.  The
+    'reference' is the CPU oracle (the reference cannot run here); its 4096-spp render of the Sponza stand-in at
+    192x108 is the committed fixture tests/golden/sponza_standin_192x108_4096spp.npz (make_golden_converged.py).
+    Tolerance: rel-MSE = mean((a-b)^2 / (b^2 + 1e-2)) <= 1e-3 -- and because the build pins every fp32 expression
+    and applies samples in accumulated_count order, the single-GPU image is in fact bit-identical.  The 8-way sample
+    partition (mean of 8 means of 512 samples, the multi-GPU combine) differs only by fp32 summation order."""
+    from helpers import rel_mse
+    from path_tracer_amd import capi, host
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sponza_standin_192x108_4096spp.npz"))
+    want = g["albedo"]
+    W, H, SPP = 192, 108, int(g["spp"])
+    ing = ingest(("sponza/Sponza.gltf", (0, 0, 0)), decode_image=host.decode_image)
+    ctx = gpu_ctx_factory(limits=_big_limits())
+    upload(ctx, ing, oracle)
+    cam = oracle.camera_matrices([-8.0, 1.6, 0.0], oracle.yaw_quat(-90.0), np.deg2rad(np.float32(70.0)), W / H, 0.1, 1000.0)
+    got = gpu_render(ctx, oracle, cam, W, H, SPP)
+    err = rel_mse(got["albedo"], want)
+    assert err <= 1e-3, err
+    assert np.array_equal(got["albedo"][..., :3].view(np.uint32), want.view(np.uint32)), "expected bit-identical, rel-MSE %g" % err
+    st = ctx.stats()
+    # 8-way spp partition on one device: slice g renders samples [512 g, 512 g + 512) into its own running mean
+    acc = np.zeros((H, W, 4), np.float64)
+    for part in range(8):
+        p = capi.default_params(rng_sample_offset=part * (SPP // 8))
+        acc += gpu_render(ctx, oracle, cam, W, H, SPP // 8, params=p)["albedo"]
+    combined = (acc / 8.0).astype(np.float32)
+    err8 = rel_mse(combined, want)
+    assert err8 <= 1e-3 and err8 < 1e-9, err8
+    assert st["samples"] >= W * H * SPP

@@ -108,7 +108,7 @@ def test_headless_cli_matches_the_host_renderer(tmp_path):
     assert r.returncode == 0, r.stderr
     import json
     rep = json.loads(r.stdout.strip().splitlines()[-1])
-    assert rep["samples"] == 96 * 64 * 6 and rep["rays"] > rep["samples"]      # 1 settle frame + 5 accumulated
+    assert rep["samples"] == 96 * 64 * 7 and rep["rays"] > rep["samples"]      # 2 settle frames + 5 accumulated
 
     R = host.Renderer(96, 64)
     R.import_gltf(gltf)
@@ -116,7 +116,9 @@ def test_headless_cli_matches_the_host_renderer(tmp_path):
     R.set_seed(19088743, True)
     R.set_params(capi.default_params(max_depth=8))
     R.record_commands()
+    R.record_commands()
     R.record_commands_batch(5)
+    assert R.accumulated_count == 5
     alb, nrm, dep = R.read_image(capi.IMAGE_ALBEDO), R.read_image(capi.IMAGE_NORMAL), R.read_image(capi.IMAGE_DEPTH)
     assert np.array_equal(read_pfm(out + "_albedo.pfm").view(np.uint32), alb[..., :3].view(np.uint32))
     assert np.array_equal(read_pfm(out + "_normal.pfm").view(np.uint32), nrm[..., :3].view(np.uint32))
@@ -127,6 +129,26 @@ def test_headless_cli_matches_the_host_renderer(tmp_path):
     # an existing output is not overwritten (renderer.rs:752-754)
     r = subprocess.run([cli, gltf, "--res", "8x8", "--spp", "1", "--out", out], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "exists" in r.stderr.lower()
+
+
+def test_headless_cli_lit_matches_oracle(oracle, tmp_path):
+    """ptx-render --lit (implies --no-ref-quirks): the PFM radiance equals the oracle's lit render of the same file."""
+    import subprocess
+    from helpers import cornell_lit
+    from path_tracer_amd import build
+    cli = build.build_cli()
+    gltf = os.path.join(ASSETS, "cornell_lit/cornell_lit.gltf")
+    out = str(tmp_path / "lit")
+    r = subprocess.run([cli, gltf, "--lit", "--res", "64x64", "--spp", "4", "--seed", "19088743", "--depth", "8",
+                        "--camera", "0,1.0,3.9", "--yaw", "0", "--fov", "40", "--out", out],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    sc = oracle.scene_from_ingest(cornell_lit(), options=oracle.SCENE_WORLD_NORMALS | oracle.SCENE_TEXTURE_TIMES_FACTOR,
+                                  with_material_ext=True)
+    cam = oracle.camera_matrices([0, 1.0, 3.9], oracle.yaw_quat(0.0), np.deg2rad(np.float32(40.0)), 1.0, 0.1, 1000.0)
+    want = sc.render(cam, 64, 64, 4, SEED, params=oracle.default_params(max_depth=8, integrator=oracle.INTEGRATOR_LIT))
+    assert np.array_equal(read_pfm(out + "_albedo.pfm").view(np.uint32), want["albedo"][..., :3].view(np.uint32))
+    assert np.array_equal(read_pfm(out + "_normal.pfm").view(np.uint32), want["normal"][..., :3].view(np.uint32))
 
 
 def test_entity_motion_refits_and_matches_oracle(oracle):
