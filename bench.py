@@ -30,6 +30,9 @@ WORKLOADS = {
     # scene, (gltf, offset) list, camera pos, yaw deg, fov deg, resolution
     "sponza_1080p": dict(items=[("sponza/Sponza.gltf", (0, 0, 0))], pos=[-8.0, 1.6, 0.0], yaw=-90.0, fov=70.0,
                          res=(1920, 1080), geometry="procedural stand-in (Sponza.bin is missing from the reference checkout)"),
+    # BASELINE.json config 5 (the 4096-spp convergence run is this workload repeated; tests/ hold the converged-image check)
+    "sponza_4k": dict(items=[("sponza/Sponza.gltf", (0, 0, 0))], pos=[-8.0, 1.6, 0.0], yaw=-90.0, fov=70.0,
+                      res=(3840, 2160), geometry="procedural stand-in (Sponza.bin is missing from the reference checkout)"),
     "spheres_720p": dict(items=[("spheres/spheres.gltf", (0, 0, 0))], pos=[7.0, 2.0, 0.0], yaw=90.0, fov=70.0,
                          res=(1280, 720), geometry="procedural stand-in (spheres.bin is missing from the reference checkout)"),
     "lion_boulder_1080p": dict(items=[("lion_head_2k/lion_head_2k.gltf", (2, 0, 0)), ("boulder_01_2k/boulder_01_2k.gltf", (-2, 0, 0))],
