@@ -38,6 +38,7 @@ struct Bvh8 {
     std::vector<Bvh8Node> nodes;     // nodes[0] is the root (empty vector: empty scene)
     std::vector<uint32_t> tri_order; // leaf order -> input triangle index
     uint32_t depth = 0;              // levels of Bvh8Node below and including the root
+    std::vector<uint32_t> level_first; // nodes are stored level by level (breadth first): first node of each level, then nodes.size()
 };
 
 // `verts`: 9 floats per triangle (world space).  Deterministic for a given input.
@@ -47,6 +48,6 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads);
 // Same tree, moved triangles (same indexing as the build's input): recomputes every box bottom-up.
 // Returns false if the set of finite triangles changed (the caller rebuilds).  *sah: sum of node
 // half-areas / root half-area, a traversal-cost figure to compare against the freshly built tree's.
-bool refit_bvh8(Bvh8 &bvh, const float *verts, size_t n_tris, double *sah);
+bool refit_bvh8(Bvh8 &bvh, const float *verts, size_t n_tris, double *sah, int n_threads = 1);
 
 }  // namespace ptx

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <future>
 #include <limits>
+#include <thread>
 
 namespace ptx {
 namespace {
@@ -167,36 +168,65 @@ void set_child_planes(Bvh8Node &nd, int s, const Box &ch)
     }
 }
 
+// static slices of [0, n) over up to n_threads threads
+template <class F> void par_for(size_t n, int n_threads, F &&fn)
+{
+    int nt = std::max(1, std::min(n_threads, 64));
+    if (nt == 1 || n < 4096) { fn((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    size_t per = (n + (size_t)nt - 1) / (size_t)nt;
+    for (int t = 0; t < nt; ++t) {
+        size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
+        if (lo < hi) th.emplace_back([=, &fn] { fn(lo, hi); });
+    }
+    for (std::thread &t : th) t.join();
+}
+
 // Boxes of the finite triangles, padded so that box culling can never contradict the triangle test (the
 // test's edge functions are exact only up to a few ulps of the coordinate magnitude).  Returns the indices
 // of the finite triangles; a triangle with a non-finite coordinate can never be hit and is left out.
-std::vector<uint32_t> padded_tri_boxes(const float *verts, size_t n_tris, std::vector<Box> &tri_box)
+std::vector<uint32_t> padded_tri_boxes(const float *verts, size_t n_tris, std::vector<Box> &tri_box, int n_threads = 1)
 {
     tri_box.resize(n_tris);
-    std::vector<uint32_t> order; order.reserve(n_tris);
-    float scene_ext = 0.0f;
-    Box sb; sb.reset();
-    for (size_t t = 0; t < n_tris; ++t) {
-        const float *v = verts + t * 9;
-        bool fin = true;
-        for (int k = 0; k < 9; ++k) fin = fin && std::isfinite(v[k]);
-        if (!fin) { tri_box[t].reset(); continue; }
-        Box b; b.reset();
-        for (int k = 0; k < 3; ++k)
-            for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], v[k * 3 + a]); b.hi[a] = std::max(b.hi[a], v[k * 3 + a]); }
-        tri_box[t] = b; sb.grow(b);
-        order.push_back((uint32_t)t);
-    }
-    if (order.empty()) return order;
-    for (int a = 0; a < 3; ++a) scene_ext = std::max(scene_ext, sb.hi[a] - sb.lo[a]);
-    for (uint32_t t : order) {
-        Box &b = tri_box[t];
-        for (int a = 0; a < 3; ++a) {
-            float m = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
-            float pad = 2e-5f * m + 1e-6f * scene_ext + 1e-30f;
-            b.lo[a] -= pad; b.hi[a] += pad;
+    int nt = std::max(1, std::min(n_threads, 64));
+    std::vector<Box> part((size_t)nt);
+    for (Box &b : part) b.reset();
+    size_t per = (n_tris + (size_t)nt - 1) / (size_t)nt;
+    par_for((size_t)nt, n_tris < 4096 ? 1 : nt, [&](size_t plo, size_t phi) {
+        for (size_t pi = plo; pi < phi; ++pi) {
+            size_t lo = std::min(n_tris, pi * per), hi = std::min(n_tris, lo + per);
+            Box sb; sb.reset();
+            for (size_t t = lo; t < hi; ++t) {
+                const float *v = verts + t * 9;
+                bool fin = true;
+                for (int k = 0; k < 9; ++k) fin = fin && std::isfinite(v[k]);
+                if (!fin) { tri_box[t].reset(); continue; }
+                Box b; b.reset();
+                for (int k = 0; k < 3; ++k)
+                    for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], v[k * 3 + a]); b.hi[a] = std::max(b.hi[a], v[k * 3 + a]); }
+                tri_box[t] = b; sb.grow(b);
+            }
+            part[pi] = sb;
         }
-    }
+    });
+    std::vector<uint32_t> order; order.reserve(n_tris);
+    for (size_t t = 0; t < n_tris; ++t) if (tri_box[t].lo[0] <= tri_box[t].hi[0]) order.push_back((uint32_t)t);
+    if (order.empty()) return order;
+    Box sb; sb.reset();
+    for (const Box &b : part) if (b.lo[0] <= b.hi[0]) sb.grow(b);
+    float scene_ext = 0.0f;
+    for (int a = 0; a < 3; ++a) scene_ext = std::max(scene_ext, sb.hi[a] - sb.lo[a]);
+    par_for(n_tris, n_threads, [&](size_t lo, size_t hi) {
+        for (size_t t = lo; t < hi; ++t) {
+            Box &b = tri_box[t];
+            if (!(b.lo[0] <= b.hi[0])) continue;
+            for (int a = 0; a < 3; ++a) {
+                float m = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
+                float pad = 2e-5f * m + 1e-6f * scene_ext + 1e-30f;
+                b.lo[a] -= pad; b.hi[a] += pad;
+            }
+        }
+    });
     return order;
 }
 
@@ -209,7 +239,7 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
     if (n_tris > 1000000000u) return false;
 
     std::vector<Box> tri_box;
-    std::vector<uint32_t> order = padded_tri_boxes(verts, n_tris, tri_box);
+    std::vector<uint32_t> order = padded_tri_boxes(verts, n_tris, tri_box, n_threads);
     if (order.empty()) return true;
     std::vector<float> centroid(n_tris * 3);
     for (uint32_t t : order)
@@ -283,9 +313,11 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
     queue.push_back({0u, 1u});
     out.nodes.resize(1);
     out.tri_order.reserve(n);
+    out.level_first.clear();
     for (size_t qi = 0; qi < queue.size(); ++qi) {
         const Node2 &src = b2.nodes[queue[qi].node2];
         uint32_t depth = queue[qi].depth;
+        if (depth > out.depth) out.level_first.push_back((uint32_t)qi);      // breadth-first queue: depths never decrease
         out.depth = std::max(out.depth, depth);
 
         uint32_t kids[8]; int nk = 0;
@@ -351,6 +383,7 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
         out.nodes.resize(out.nodes.size() + n_inner);
         out.nodes[qi] = nd;
     }
+    out.level_first.push_back((uint32_t)out.nodes.size());
     return true;
 }
 
@@ -358,16 +391,17 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
 // parents, so one backward sweep recomputes every node's box from its leaf triangles / inner children and
 // re-quantises the child planes.  `sah` = sum of the node half-areas relative to the root's: the caller
 // compares it with the value right after a build to decide when a moved scene deserves a full rebuild.
-bool refit_bvh8(Bvh8 &bvh, const float *verts, size_t n_tris, double *sah)
+bool refit_bvh8(Bvh8 &bvh, const float *verts, size_t n_tris, double *sah, int n_threads)
 {
     if (sah) *sah = 0.0;
     if (bvh.nodes.empty()) return true;
     std::vector<Box> tri_box;
-    std::vector<uint32_t> finite = padded_tri_boxes(verts, n_tris, tri_box);
+    std::vector<uint32_t> finite = padded_tri_boxes(verts, n_tris, tri_box, n_threads);
     if (finite.size() != bvh.tri_order.size()) return false;      // a triangle became (non-)finite: rebuild
+    for (uint32_t t : bvh.tri_order)
+        if (!(tri_box[t].lo[0] <= tri_box[t].hi[0])) return false;  // a referenced triangle is no longer finite
     std::vector<Box> node_box(bvh.nodes.size());
-    double area_sum = 0.0;
-    for (size_t i = bvh.nodes.size(); i-- > 0;) {
+    auto refit_node = [&](size_t i) {
         Bvh8Node &nd = bvh.nodes[i];
         Box child[8]; bool used[8];
         Box nb; nb.reset();
@@ -380,11 +414,7 @@ bool refit_bvh8(Bvh8 &bvh, const float *verts, size_t n_tris, double *sah)
                 cb = node_box[nd.child_base + rel];
             } else {
                 uint32_t off = nd.meta[s] & 31u, cnt = (uint32_t)__builtin_popcount((uint32_t)nd.meta[s] >> 5);
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    uint32_t t = bvh.tri_order[nd.tri_base + off + k];
-                    if (!(tri_box[t].lo[0] <= tri_box[t].hi[0])) return false;   // that triangle is no longer finite
-                    cb.grow(tri_box[t]);
-                }
+                for (uint32_t k = 0; k < cnt; ++k) cb.grow(tri_box[bvh.tri_order[nd.tri_base + off + k]]);
             }
             child[s] = cb; nb.grow(cb);
         }
@@ -394,8 +424,20 @@ bool refit_bvh8(Bvh8 &bvh, const float *verts, size_t n_tris, double *sah)
             if (used[s]) set_child_planes(nd, s, child[s]);
             else for (int a = 0; a < 3; ++a) { nd.qlo[a][s] = 0; nd.qhi[a][s] = 0; }
         }
-        area_sum += (double)nb.half_area();
+    };
+    // deepest level first; the nodes of one level are independent of each other
+    std::vector<uint32_t> lf = bvh.level_first;
+    if (lf.size() < 2 || lf.front() != 0 || lf.back() != bvh.nodes.size()) { lf.clear(); lf.push_back(0); }   // unknown layout: one node at a time, backwards
+    if (lf.size() >= 2) {
+        for (size_t l = lf.size() - 1; l-- > 0;) {
+            size_t first = lf[l], count = lf[l + 1] - lf[l];
+            par_for(count, n_threads, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) refit_node(first + i); });
+        }
+    } else {
+        for (size_t i = bvh.nodes.size(); i-- > 0;) refit_node(i);
     }
+    double area_sum = 0.0;
+    for (const Box &b : node_box) area_sum += (double)b.half_area();
     double root = (double)node_box[0].half_area();
     if (sah) *sah = root > 0.0 ? area_sum / root : 0.0;
     return true;

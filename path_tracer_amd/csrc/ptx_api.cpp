@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -449,6 +450,14 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
     if (n > c->limits.max_offsets) return fail(c, PTX_ERR_CAPACITY, "ptx_set_instances: offsets buffer overflow");
     if (int r = bind(c)) return r;
 
+    static const bool verbose = getenv("PTX_VERBOSE") != nullptr;
+    auto tick = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!verbose) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ptx] set_instances %-10s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
+        tick = now;
+    };
     uint64_t n_tris = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const ptx_instance &in = inst[i];
@@ -487,6 +496,7 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
             }
         });
     }
+    lap("flatten");
     // Same entities, new transforms (the reference rebuilds its TLAS every frame, renderer.rs:961, and wants not
     // to: todo.md:3): keep the tree and refit its boxes, unless the moved scene has made it too loose.
     bool refitted = false;
@@ -495,7 +505,8 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
         for (uint32_t i = 0; i < n && same; ++i)
             same = inst[i].geometry == c->built_instances[i].geometry && memcmp(&inst[i].off, &c->built_instances[i].off, sizeof(ptx_offsets)) == 0;
         double sah = 0.0;
-        if (same && refit_bvh8(c->bvh, wv.data(), n_tris, &sah) && sah <= c->built_sah * kRefitSahLimit) refitted = true;
+        int rthreads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (same && refit_bvh8(c->bvh, wv.data(), n_tris, &sah, rthreads) && sah <= c->built_sah * kRefitSahLimit) refitted = true;
     }
     Bvh8 &bvh = c->bvh;
     if (!refitted) {
@@ -504,12 +515,13 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
         if (!build_bvh8(wv.data(), n_tris, bvh, threads)) return fail(c, PTX_ERR_INVALID, "ptx_set_instances: BVH build failed");
         if (bvh.depth > kMaxBvhDepth) return fail(c, PTX_ERR_CAPACITY, "ptx_set_instances: BVH deeper than the traversal stack");
         Bvh8 probe = bvh;                     // the cost figure of the fresh tree, by the same routine that refits
-        if (!refit_bvh8(probe, wv.data(), n_tris, &c->built_sah)) c->built_sah = 0.0;
+        if (!refit_bvh8(probe, wv.data(), n_tris, &c->built_sah, threads)) c->built_sah = 0.0;
         c->n_builds++;
     } else {
         c->n_refits++;
     }
     c->built_instances.assign(inst, inst + n);
+    lap(refitted ? "refit" : "build");
 
     const bool world_normals = (c->scene_options & PTX_SCENE_WORLD_NORMALS) != 0;
     std::vector<float> cof((size_t)n * 9);
@@ -560,6 +572,7 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
         lm.transmission = c->material_ext[i].transmission; lm.ior = c->material_ext[i].ior;
     }
 
+    lap("lights");
     uint64_t nt = bvh.tri_order.size();
     if (int r = ensure_staging(c, nt * (sizeof(TriRec) + sizeof(ShadeRec)) + 256)) return r;
     ShadeRec *shade = reinterpret_cast<ShadeRec *>(c->staging);                 // 128-byte records first (alignment)
@@ -594,7 +607,9 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
     }
     });
 
+    lap("pack");
     if (int r = sync_all(c)) return r;
+    lap("sync");
     dfree(c->d_lit_materials); dfree(c->d_lights); dfree(c->d_light_cdf);
     c->n_lights = 0;
     c->scene_ready = false;
@@ -639,6 +654,7 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
     }
     c->n_instances = n;
     c->scene_ready = true;
+    lap("upload");
     return PTX_OK;
 }
 

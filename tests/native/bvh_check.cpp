@@ -42,7 +42,7 @@ void *bvhcheck_create(const float *verts, const uint32_t *ids, uint64_t n_tris, 
 int bvhcheck_refit(void *h, const float *verts, const uint32_t *ids, uint64_t n_tris, double *sah)
 {
     Check *c = (Check *)h;
-    if (!refit_bvh8(c->bvh, verts, n_tris, sah)) return 0;
+    if (!refit_bvh8(c->bvh, verts, n_tris, sah, 4)) return 0;
     for (size_t i = 0; i < c->tris.size(); ++i) {
         uint32_t t = c->bvh.tri_order[i];
         TriRec &r = c->tris[i];

@@ -109,7 +109,7 @@ int main(int argc, char **argv)
             // move everything (finite triangles stay finite) and refit
             for (size_t t = 0; t < n; ++t) for (int k = 0; k < 9; ++k) v[t * 9 + k] = v[t * 9 + k] * 1.1f + (k % 3 == 0 ? 0.5f : 0.0f);
             double sah = 0;
-            if (!refit_bvh8(bvh, v.data(), n, &sah)) { fprintf(stderr, "refit failed\n"); return 3; }
+            if (!refit_bvh8(bvh, v.data(), n, &sah, 4)) { fprintf(stderr, "refit failed\n"); return 3; }
         }
     }
     printf("images decoded %d rejected %d; json parsed %d thrown %d; bvh hits %llu\n", decoded, rejected, parsed, thrown, (unsigned long long)hits);
