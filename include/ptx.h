@@ -151,6 +151,7 @@ typedef struct {
     uint64_t shadow_rays;                  /* lit integrator: occlusion queries (not counted in rays) */
     uint64_t lights;                       /* emissive triangles in the light table */
     uint64_t bvh_builds, bvh_refits;       /* acceleration-structure builds / refits since ptx_create */
+    uint64_t bvh_device_refits;            /* of the refits, those done entirely on the GPU */
 } ptx_stats;
 
 typedef struct ptx_context ptx_context;

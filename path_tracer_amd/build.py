@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libptx_amd.so")
-SOURCES = ["ptx_api.cpp", "ptx_kernels.hip", "bvh_build.cpp", "ptx_rccl.cpp"]
+SOURCES = ["ptx_api.cpp", "ptx_kernels.hip", "ptx_refit.hip", "bvh_build.cpp", "ptx_rccl.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: shading / triangle-test arithmetic must round exactly like the CPU oracle's.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fPIC",

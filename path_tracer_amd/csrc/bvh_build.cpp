@@ -2,6 +2,7 @@
 // Replaces the driver-side BLAS/TLAS builds of the reference (scene/geometry/mod.rs:136-278,
 // renderer.rs:1196-1388).  Plain C++17, no HIP.
 #include "bvh8.h"
+#include "bvh_quant.h"
 
 #include <algorithm>
 #include <atomic>
@@ -14,23 +15,6 @@
 
 namespace ptx {
 namespace {
-
-struct Box {
-    float lo[3], hi[3];
-    void reset()
-    {
-        for (int a = 0; a < 3; ++a) { lo[a] = std::numeric_limits<float>::infinity(); hi[a] = -lo[a]; }
-    }
-    void grow(const Box &b)
-    {
-        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); }
-    }
-    float half_area() const
-    {
-        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-        return dx * dy + dy * dz + dz * dx;
-    }
-};
 
 float env_float(const char *name, float dflt);
 
@@ -137,37 +121,6 @@ float env_float(const char *name, float dflt)
     return e ? (float)atof(e) : dflt;
 }
 
-inline float step_of(uint8_t e) { uint32_t u = (uint32_t)e << 23; float f; memcpy(&f, &u, 4); return f; }
-
-// quantisation frame of a node: origin = low corner, per-axis power-of-two step covering the extent in 255 steps
-void set_node_frame(Bvh8Node &nd, const Box &box)
-{
-    for (int a = 0; a < 3; ++a) {
-        nd.p[a] = box.lo[a];
-        float ext = box.hi[a] - box.lo[a];
-        int e; float m = std::frexp(ext / 255.0f, &e);   // ext/255 = m * 2^e, m in [0.5,1)
-        (void)m;
-        int be = e + 127;                                // step = 2^e >= ext/255
-        be = std::min(254, std::max(1, be));
-        while (be < 254 && !(nd.p[a] + step_of((uint8_t)be) * 255.0f >= box.hi[a])) ++be;
-        nd.e[a] = (uint8_t)be;
-    }
-}
-
-// conservative 8-bit planes of child box `ch` in slot s: the decoded planes (fp32: p + q*step) enclose it
-void set_child_planes(Bvh8Node &nd, int s, const Box &ch)
-{
-    for (int a = 0; a < 3; ++a) {
-        float st = step_of(nd.e[a]);
-        int lo = (int)std::floor(((double)ch.lo[a] - (double)nd.p[a]) / (double)st);
-        int hi = (int)std::ceil(((double)ch.hi[a] - (double)nd.p[a]) / (double)st);
-        lo = std::min(255, std::max(0, lo)); hi = std::min(255, std::max(0, hi));
-        while (lo > 0 && nd.p[a] + (float)lo * st > ch.lo[a]) --lo;
-        while (hi < 255 && nd.p[a] + (float)hi * st < ch.hi[a]) ++hi;
-        nd.qlo[a][s] = (uint8_t)lo; nd.qhi[a][s] = (uint8_t)hi;
-    }
-}
-
 // static slices of [0, n) over up to n_threads threads
 template <class F> void par_for(size_t n, int n_threads, F &&fn)
 {
@@ -197,13 +150,8 @@ std::vector<uint32_t> padded_tri_boxes(const float *verts, size_t n_tris, std::v
             size_t lo = std::min(n_tris, pi * per), hi = std::min(n_tris, lo + per);
             Box sb; sb.reset();
             for (size_t t = lo; t < hi; ++t) {
-                const float *v = verts + t * 9;
-                bool fin = true;
-                for (int k = 0; k < 9; ++k) fin = fin && std::isfinite(v[k]);
-                if (!fin) { tri_box[t].reset(); continue; }
-                Box b; b.reset();
-                for (int k = 0; k < 3; ++k)
-                    for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], v[k * 3 + a]); b.hi[a] = std::max(b.hi[a], v[k * 3 + a]); }
+                Box b;
+                if (!tri_raw_box(verts + t * 9, b)) { tri_box[t].reset(); continue; }
                 tri_box[t] = b; sb.grow(b);
             }
             part[pi] = sb;
@@ -219,12 +167,8 @@ std::vector<uint32_t> padded_tri_boxes(const float *verts, size_t n_tris, std::v
     par_for(n_tris, n_threads, [&](size_t lo, size_t hi) {
         for (size_t t = lo; t < hi; ++t) {
             Box &b = tri_box[t];
-            if (!(b.lo[0] <= b.hi[0])) continue;
-            for (int a = 0; a < 3; ++a) {
-                float m = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
-                float pad = 2e-5f * m + 1e-6f * scene_ext + 1e-30f;
-                b.lo[a] -= pad; b.hi[a] += pad;
-            }
+            if (!b.valid()) continue;
+            pad_tri_box(b, scene_ext);
         }
     });
     return order;
@@ -402,28 +346,7 @@ bool refit_bvh8(Bvh8 &bvh, const float *verts, size_t n_tris, double *sah, int n
         if (!(tri_box[t].lo[0] <= tri_box[t].hi[0])) return false;  // a referenced triangle is no longer finite
     std::vector<Box> node_box(bvh.nodes.size());
     auto refit_node = [&](size_t i) {
-        Bvh8Node &nd = bvh.nodes[i];
-        Box child[8]; bool used[8];
-        Box nb; nb.reset();
-        for (int s = 0; s < 8; ++s) {
-            used[s] = nd.meta[s] != 0;
-            if (!used[s]) continue;
-            Box cb; cb.reset();
-            if ((nd.imask >> s) & 1u) {
-                uint32_t rel = (uint32_t)__builtin_popcount(nd.imask & ((1u << s) - 1u));
-                cb = node_box[nd.child_base + rel];
-            } else {
-                uint32_t off = nd.meta[s] & 31u, cnt = (uint32_t)__builtin_popcount((uint32_t)nd.meta[s] >> 5);
-                for (uint32_t k = 0; k < cnt; ++k) cb.grow(tri_box[bvh.tri_order[nd.tri_base + off + k]]);
-            }
-            child[s] = cb; nb.grow(cb);
-        }
-        node_box[i] = nb;
-        set_node_frame(nd, nb);
-        for (int s = 0; s < 8; ++s) {
-            if (used[s]) set_child_planes(nd, s, child[s]);
-            else for (int a = 0; a < 3; ++a) { nd.qlo[a][s] = 0; nd.qhi[a][s] = 0; }
-        }
+        node_box[i] = refit_one_node(bvh.nodes[i], node_box.data(), [&](uint32_t k) { return tri_box[bvh.tri_order[k]]; });
     };
     // deepest level first; the nodes of one level are independent of each other
     std::vector<uint32_t> lf = bvh.level_first;

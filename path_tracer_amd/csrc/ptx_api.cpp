@@ -72,11 +72,16 @@ struct ptx_context {
     LightRec *d_lights = nullptr; float *d_light_cdf = nullptr; uint32_t n_lights = 0;
     uint32_t built_options = 0;                   // scene options the current device scene was built with
     void *staging = nullptr; uint64_t staging_bytes = 0;   // pinned host staging for scene uploads
+    // device refit (ptx_refit.hip): what the kernels need to re-flatten and refit without the host
+    RefitLeafSrc *d_leaf_src = nullptr; ptx_vertex *d_vertices = nullptr; uint64_t n_dev_vertices = 0;
+    RefitInstance *d_refit_inst = nullptr; uint64_t cap_refit_inst = 0;
+    void *d_raw_box = nullptr, *d_node_box = nullptr; RefitState *d_refit_state = nullptr;
+    bool refit_ready = false;
     uint64_t cap_nodes = 0, cap_tris = 0;         // element capacities of d_nodes / d_tris + d_shade (reused across rebuilds)
     Bvh8 bvh;                                     // host copy of the acceleration structure (refit on instance motion)
     std::vector<ptx_instance> built_instances;    // the list it was built / last refitted for
     double built_sah = 0.0;                       // refit_bvh8's cost figure right after the build
-    uint64_t n_builds = 0, n_refits = 0;
+    uint64_t n_builds = 0, n_refits = 0, n_device_refits = 0;
     uint32_t bvh_depth = 0;
     bool scene_ready = false;
     bool textures_dirty = true;
@@ -323,6 +328,7 @@ int ptx_destroy(ptx_context *c)
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_textures); dfree(c->d_lut);
     dfree(c->d_lit_materials); dfree(c->d_lights); dfree(c->d_light_cdf);
     if (c->staging) (void)hipHostFree(c->staging);
+    dfree(c->d_leaf_src); dfree(c->d_vertices); dfree(c->d_refit_inst); dfree(c->d_raw_box); dfree(c->d_node_box); dfree(c->d_refit_state);
     dfree(c->d_albedo); dfree(c->d_normal); dfree(c->d_depth); dfree(c->d_ids);
     for (int i = 0; i < kMaxSets; ++i) {
         PathSet &ps = c->sets[i];
@@ -443,6 +449,71 @@ int ptx_update_instances(ptx_context *c, const ptx_instance *inst, uint32_t n) {
 // A moved scene keeps its tree while the refitted tree's cost figure stays below this multiple of the built tree's.
 static constexpr double kRefitSahLimit = 1.6;
 
+// Instance motion on the device: new transforms up (96 B per instance), k_refit_pack re-flattens the leaf triangles in
+// place, k_refit_nodes refits level by level from the deepest, the cost figure comes back (32 B).  `ok` = false: the
+// moved scene needs the host path (a non-finite triangle, or the tree has become too loose) -- the device scene is
+// then rebuilt from scratch by the caller.
+static int device_refit(ptx_context *c, const ptx_instance *inst, uint32_t n, bool &ok)
+{
+    ok = false;
+    std::vector<RefitInstance> ri(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        memcpy(ri[i].xform, inst[i].xform, 48);
+        normal_matrix(inst[i].xform, ri[i].cof);
+        ri[i]._pad[0] = ri[i]._pad[1] = ri[i]._pad[2] = 0.0f;
+    }
+    if (n > c->cap_refit_inst) {
+        dfree(c->d_refit_inst); c->cap_refit_inst = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_refit_inst, (size_t)n * sizeof(RefitInstance)));
+        c->cap_refit_inst = n;
+    }
+    if (int r = sync_all(c)) return r;          // frames in flight read the triangles and nodes that are about to move
+    RefitState st; refit_state_reset(&st);
+    HIP_TRY(c, hipMemcpyAsync(c->d_refit_state, &st, sizeof st, hipMemcpyHostToDevice, c->stream));
+    if (n) HIP_TRY(c, hipMemcpyAsync(c->d_refit_inst, ri.data(), (size_t)n * sizeof(RefitInstance), hipMemcpyHostToDevice, c->stream));
+    launch_refit_pack(c->stream, c->d_leaf_src, c->d_vertices, c->d_refit_inst, (uint32_t)c->n_tris,
+                      (c->built_options & PTX_SCENE_WORLD_NORMALS) != 0, c->d_tris, c->d_shade, c->d_raw_box, c->d_refit_state);
+    const std::vector<uint32_t> &lf = c->bvh.level_first;
+    for (size_t l = lf.size() - 1; l-- > 0;)
+        launch_refit_nodes(c->stream, c->d_nodes, c->d_node_box, c->d_raw_box, lf[l], lf[l + 1] - lf[l], c->d_refit_state);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(&st, c->d_refit_state, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double sah = st.root_area > 0.0 ? st.area_sum / st.root_area : 0.0;
+    if (st.non_finite || !(sah <= c->built_sah * kRefitSahLimit)) return PTX_OK;
+    if (getenv("PTX_REFIT_VERIFY")) {
+        // developer / test check: the host refit of the same motion must give byte-identical nodes and triangles
+        uint64_t n_tris = 0;
+        for (uint32_t i = 0; i < n; ++i) n_tris += c->geometries[inst[i].geometry].n_indices / 3;
+        std::vector<float> wv(n_tris * 9);
+        uint64_t k = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const Geometry &g = c->geometries[inst[i].geometry];
+            for (uint64_t p = 0; p < g.n_indices / 3; ++p, ++k)
+                for (int v = 0; v < 3; ++v)
+                    xform_point(inst[i].xform, c->vertices[g.first_vertex + c->indices[g.first_index + p * 3 + v]].position, &wv[k * 9 + v * 3]);
+        }
+        Bvh8 host = c->bvh;
+        double hsah = 0.0;
+        if (!refit_bvh8(host, wv.data(), n_tris, &hsah, 4)) return fail(c, PTX_ERR_STATE, "PTX_REFIT_VERIFY: host refit refused what the device refit accepted");
+        std::vector<Bvh8Node> dn(host.nodes.size());
+        std::vector<TriRec> dt(c->n_tris);
+        HIP_TRY(c, hipMemcpy(dn.data(), c->d_nodes, dn.size() * sizeof(Bvh8Node), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(dt.data(), c->d_tris, dt.size() * sizeof(TriRec), hipMemcpyDeviceToHost));
+        if (memcmp(dn.data(), host.nodes.data(), dn.size() * sizeof(Bvh8Node)) != 0)
+            return fail(c, PTX_ERR_STATE, "PTX_REFIT_VERIFY: device-refitted nodes differ from the host refit");
+        for (uint64_t j = 0; j < c->n_tris; ++j)
+            if (memcmp(dt[j].v0, &wv[(uint64_t)host.tri_order[j] * 9], 12) != 0 || memcmp(dt[j].v2, &wv[(uint64_t)host.tri_order[j] * 9 + 6], 12) != 0)
+                return fail(c, PTX_ERR_STATE, "PTX_REFIT_VERIFY: device-flattened triangles differ from the host's");
+        if (!(std::fabs(hsah - sah) <= 1e-9 * std::fabs(hsah))) return fail(c, PTX_ERR_STATE, "PTX_REFIT_VERIFY: cost figures differ");
+    }
+    c->built_instances.assign(inst, inst + n);
+    c->n_refits++;
+    c->n_device_refits++;
+    ok = true;
+    return PTX_OK;
+}
+
 static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t n, bool try_refit)
 {
     if (!c) return PTX_ERR_INVALID;
@@ -476,6 +547,20 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
         n_tris += g.n_indices / 3;
     }
 
+    // Same entities, new transforms (the reference rebuilds its TLAS every frame, renderer.rs:961, and wants not
+    // to: todo.md:3): keep the tree and refit its boxes, unless the moved scene has made it too loose.
+    bool same_list = try_refit && c->scene_ready && c->built_instances.size() == n && c->built_options == c->scene_options;
+    for (uint32_t i = 0; i < n && same_list; ++i)
+        same_list = inst[i].geometry == c->built_instances[i].geometry && memcmp(&inst[i].off, &c->built_instances[i].off, sizeof(ptx_offsets)) == 0;
+    // on the device when nothing else has to change (an emitter that moves takes the light table with it: host path)
+    const bool host_refit_only = getenv("PTX_HOST_REFIT") != nullptr;
+    if (same_list && c->refit_ready && c->n_lights == 0 && !host_refit_only && c->bvh.level_first.size() >= 2) {
+        bool ok = false;
+        if (int r = device_refit(c, inst, n, ok)) return r;
+        lap("dev refit");
+        if (ok) return PTX_OK;
+    }
+
     // flatten to world space: the instance transform is applied once here instead of per ray
     std::vector<float> wv(n_tris * 9);
     std::vector<uint32_t> tri_inst(n_tris), tri_prim(n_tris);
@@ -497,16 +582,11 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
         });
     }
     lap("flatten");
-    // Same entities, new transforms (the reference rebuilds its TLAS every frame, renderer.rs:961, and wants not
-    // to: todo.md:3): keep the tree and refit its boxes, unless the moved scene has made it too loose.
     bool refitted = false;
-    if (try_refit && c->scene_ready && c->built_instances.size() == n && c->built_options == c->scene_options) {
-        bool same = true;
-        for (uint32_t i = 0; i < n && same; ++i)
-            same = inst[i].geometry == c->built_instances[i].geometry && memcmp(&inst[i].off, &c->built_instances[i].off, sizeof(ptx_offsets)) == 0;
+    if (same_list) {
         double sah = 0.0;
         int rthreads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-        if (same && refit_bvh8(c->bvh, wv.data(), n_tris, &sah, rthreads) && sah <= c->built_sah * kRefitSahLimit) refitted = true;
+        if (refit_bvh8(c->bvh, wv.data(), n_tris, &sah, rthreads) && sah <= c->built_sah * kRefitSahLimit) refitted = true;
     }
     Bvh8 &bvh = c->bvh;
     if (!refitted) {
@@ -577,6 +657,7 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
     if (int r = ensure_staging(c, nt * (sizeof(TriRec) + sizeof(ShadeRec)) + 256)) return r;
     ShadeRec *shade = reinterpret_cast<ShadeRec *>(c->staging);                 // 128-byte records first (alignment)
     TriRec *tris = reinterpret_cast<TriRec *>(shade + nt);
+    std::vector<RefitLeafSrc> leaf_src(refitted ? 0 : nt);                      // topology changed: the device refit's inputs too
     parallel_for(nt, [&](uint64_t klo, uint64_t khi) {
     for (uint64_t k = klo; k < khi; ++k) {
         uint32_t t = bvh.tri_order[k];
@@ -586,6 +667,11 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
         const ptx_vertex &a = c->vertices[g.first_vertex + ix[0]];
         const ptx_vertex &b = c->vertices[g.first_vertex + ix[1]];
         const ptx_vertex &d = c->vertices[g.first_vertex + ix[2]];
+        if (!refitted) {
+            RefitLeafSrc &ls = leaf_src[k];
+            ls.instance = tri_inst[t];
+            for (int v = 0; v < 3; ++v) ls.v[v] = (uint32_t)(g.first_vertex + ix[v]);
+        }
         TriRec &tr = tris[k];
         memcpy(tr.v0, &wv[(uint64_t)t * 9], 12); memcpy(tr.v1, &wv[(uint64_t)t * 9 + 3], 12); memcpy(tr.v2, &wv[(uint64_t)t * 9 + 6], 12);
         tr.instance = tri_inst[t]; tr.prim = tri_prim[t]; tr.material = in.off.material_offset;
@@ -651,6 +737,25 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
             HIP_TRY(c, hipMemcpy(c->d_textures, c->textures.data(), c->textures.size() * sizeof(TexDesc), hipMemcpyHostToDevice));
         }
         c->textures_dirty = false;
+    }
+    // inputs of the device refit: per leaf triangle its instance and vertices, the shared vertex buffer, scratch boxes
+    if (!refitted) {
+        c->refit_ready = false;
+        dfree(c->d_leaf_src); dfree(c->d_raw_box); dfree(c->d_node_box);
+        if (nt && c->n_nodes) {
+            HIP_TRY(c, hipMalloc((void **)&c->d_leaf_src, nt * sizeof(RefitLeafSrc)));
+            HIP_TRY(c, hipMemcpy(c->d_leaf_src, leaf_src.data(), nt * sizeof(RefitLeafSrc), hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMalloc(&c->d_raw_box, nt * (size_t)kRefitBoxBytes));
+            HIP_TRY(c, hipMalloc(&c->d_node_box, (size_t)c->n_nodes * kRefitBoxBytes));
+            if (!c->d_refit_state) HIP_TRY(c, hipMalloc((void **)&c->d_refit_state, sizeof(RefitState)));
+            if (c->n_dev_vertices != c->vertices.size()) {      // the shared vertex buffer only ever grows (scene/mod.rs:270)
+                dfree(c->d_vertices); c->n_dev_vertices = 0;
+                HIP_TRY(c, hipMalloc((void **)&c->d_vertices, c->vertices.size() * sizeof(ptx_vertex)));
+                HIP_TRY(c, hipMemcpy(c->d_vertices, c->vertices.data(), c->vertices.size() * sizeof(ptx_vertex), hipMemcpyHostToDevice));
+                c->n_dev_vertices = c->vertices.size();
+            }
+            c->refit_ready = true;
+        }
     }
     c->n_instances = n;
     c->scene_ready = true;
@@ -881,7 +986,7 @@ int ptx_get_stats(ptx_context *c, ptx_stats *s)
     s->bvh_bytes = (uint64_t)c->n_nodes * sizeof(Bvh8Node) + c->n_tris * (sizeof(TriRec) + sizeof(ShadeRec));
     s->bvh_depth = c->bvh_depth;
     s->shadow_rays = t[11]; s->lights = c->n_lights;
-    s->bvh_builds = c->n_builds; s->bvh_refits = c->n_refits;
+    s->bvh_builds = c->n_builds; s->bvh_refits = c->n_refits; s->bvh_device_refits = c->n_device_refits;
     return PTX_OK;
 }
 

@@ -139,4 +139,20 @@ void launch_accumulate_stats(hipStream_t s, const uint32_t *counters, uint32_t m
 constexpr int kNumTotals = 12;   // rays, hits, samples, nodes, tris, 6 x wave_sched, shadow rays
 void launch_scale_copy(hipStream_t s, const float4 *src, float4 *dst, uint64_t n, float scale);
 
+// ---- device refit (ptx_refit.hip): instance motion without a host round trip
+struct RefitLeafSrc { uint32_t instance; uint32_t v[3]; };                 // leaf-order triangle -> its instance and absolute vertex indices
+struct RefitInstance { float xform[12]; float cof[9]; float _pad[3]; };    // 3x4 row-major transform, normal matrix (cofactors x sign of det)
+static_assert(sizeof(RefitInstance) == 96, "RefitInstance must be 96 bytes");
+struct RefitState {
+    uint32_t ext_lo[3], ext_hi[3];    // scene extent as order-preserving uints (reset: lo = ~0, hi = 0)
+    uint32_t non_finite, _pad;        // a transformed triangle has a non-finite coordinate: the host rebuilds
+    double area_sum, root_area;       // sum of node half-areas, the root's: the cost figure of refit_bvh8
+};
+constexpr uint32_t kRefitBoxBytes = 24;   // sizeof(Box) in bvh_quant.h
+void refit_state_reset(RefitState *host_copy);
+void launch_refit_pack(hipStream_t s, const RefitLeafSrc *src, const ptx_vertex *verts, const RefitInstance *inst, uint32_t n_leaf,
+                       bool world_normals, TriRec *tris, ShadeRec *shade, void *raw_box, RefitState *state);
+void launch_refit_nodes(hipStream_t s, Bvh8Node *nodes, void *node_box, const void *raw_box, uint32_t first, uint32_t count,
+                        RefitState *state);
+
 }  // namespace ptx

@@ -151,10 +151,16 @@ def test_headless_cli_lit_matches_oracle(oracle, tmp_path):
     assert np.array_equal(read_pfm(out + "_normal.pfm").view(np.uint32), want["normal"][..., :3].view(np.uint32))
 
 
-def test_entity_motion_refits_and_matches_oracle(oracle):
-    """todo.md:3 / SURVEY 8f.4: moving an entity refits the acceleration structure (no rebuild) and the image
-    equals the oracle's render of the moved scene bit for bit; a changed entity list rebuilds."""
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_entity_motion_refits_and_matches_oracle(oracle, monkeypatch, where):
+    """todo.md:3 / SURVEY 8f.4: moving an entity refits the acceleration structure (no rebuild) -- on the GPU
+    (ptx_refit.hip; PTX_REFIT_VERIFY makes the library compare its nodes and triangles with the host refit byte for
+    byte) or on the host (PTX_HOST_REFIT) -- and the image equals the oracle's render of the moved scene bit for bit;
+    a changed entity list rebuilds."""
     import os
+    monkeypatch.setenv("PTX_REFIT_VERIFY", "1")
+    if where == "host":
+        monkeypatch.setenv("PTX_HOST_REFIT", "1")
     from helpers import ASSETS, SEED, assert_images_bit_equal, cornell
     from path_tracer_amd import capi, host
     r = host.Renderer(96, 96, 0)
@@ -175,6 +181,7 @@ def test_entity_motion_refits_and_matches_oracle(oracle):
     r.record_commands_batch(3)
     st = r.stats()
     assert st["bvh_builds"] == 1 and st["bvh_refits"] == 1
+    assert st["bvh_device_refits"] == (1 if where == "device" else 0)
     got = {k: r.read_image(v) for k, v in (("albedo", capi.IMAGE_ALBEDO), ("normal", capi.IMAGE_NORMAL),
                                            ("depth", capi.IMAGE_DEPTH), ("ids", capi.IMAGE_PRIMARY_ID))}
     cam = oracle.camera_matrices([0.0, 1.0, 3.9], oracle.yaw_quat(0.0), fov, 1.0, 0.1, 1000.0)
