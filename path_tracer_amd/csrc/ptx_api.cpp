@@ -43,6 +43,7 @@ struct PathSet {
     float4 *d_results = nullptr;
     uint32_t *d_counters = nullptr;
     hipEvent_t resolved = nullptr;                   // recorded after the set's latest resolve
+    hipEvent_t first_shade = nullptr;                // recorded after the set's latest bounce-0 shading (G-buffer / id image writes)
 };
 
 }  // namespace
@@ -97,8 +98,7 @@ struct ptx_context {
     int n_sets = 2;                         // chunks in flight (PTX_FRAMES_IN_FLIGHT; measured: 2 gives the whole gain, 3 is slower than 2 and 4)
     int next_set = 0;
     hipEvent_t last_resolved = nullptr;     // = sets[k].resolved of the most recent chunk: the next resolve waits for it
-    bool have_last_frame = false;           // camera / frame parameters of the previous render call
-    ptx_camera last_cam{};
+    hipEvent_t last_first_shade = nullptr;  // = sets[k].first_shade of the most recent chunk: the next bounce-0 shading waits for it
     uint64_t *d_totals = nullptr;           // rays, hits, samples, nodes fetched, triangles tested
 
     // profiling
@@ -145,6 +145,7 @@ int ensure_paths(ptx_context *c, PathSet &ps, uint64_t n, bool shadow_queue)
     if (!ps.stream) {
         HIP_TRY(c, hipStreamCreateWithFlags(&ps.stream, hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreateWithFlags(&ps.resolved, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&ps.first_shade, hipEventDisableTiming));
         HIP_TRY(c, hipMalloc((void **)&ps.d_counters, kNumCounters * sizeof(uint32_t)));
     }
     if (n > ps.capacity) {
@@ -335,6 +336,7 @@ int ptx_destroy(ptx_context *c)
         free_paths(ps);
         dfree(ps.d_counters);
         if (ps.resolved) (void)hipEventDestroy(ps.resolved);
+        if (ps.first_shade) (void)hipEventDestroy(ps.first_shade);
         if (ps.stream) (void)hipStreamDestroy(ps.stream);
     }
     dfree(c->d_totals);
@@ -771,7 +773,6 @@ int ptx_resize(ptx_context *c, uint32_t w, uint32_t h)
     if (w == 0 || h == 0 || (uint64_t)w * h > 0x40000000ull) return fail(c, PTX_ERR_INVALID, "ptx_resize: bad extent");
     if (int r = bind(c)) return r;
     if (int r = sync_all(c)) return r;
-    c->have_last_frame = false;
     dfree(c->d_albedo); dfree(c->d_normal); dfree(c->d_depth); dfree(c->d_ids);
     c->width = c->height = 0;
     uint64_t np = (uint64_t)w * h;
@@ -822,11 +823,10 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
     f.tex_times_factor = (c->built_options & PTX_SCENE_TEXTURE_TIMES_FACTOR) ? 1u : 0u;
     const uint32_t bounces = std::max(1u, p.max_depth);
 
-    // Chunks normally overlap with the chunks before them (other path sets, other streams).  A frame that
-    // rewrites the G-buffers or the id image with NEW content -- accumulated_count 0, or a camera that moved --
-    // first waits for everything before it, so that its writes land last.
-    const bool fresh = u->accumulated_count == 0 || !c->have_last_frame || memcmp(&c->last_cam, cam, sizeof *cam) != 0;
-    c->last_cam = *cam; c->have_last_frame = true;
+    // Chunks overlap with the chunks before them (other path sets, other streams).  Two orders are kept by events:
+    // the bounce-0 shading passes -- the only writers of the G-buffers and the id image -- run chunk after chunk, so
+    // a frame with a moved camera or a restarted accumulation lands after its predecessors; and the resolves run
+    // chunk after chunk, so every pixel receives its samples in accumulated_count order.
 
     for (uint32_t s0 = 0; s0 < n_samples; s0 += (uint32_t)chunk) {
         uint32_t ns = (uint32_t)std::min<uint64_t>(chunk, n_samples - s0);
@@ -839,7 +839,6 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
         // traversal kernels share the chip instead of queueing behind each other's persistent grid (1080p frame
         // 8.16 -> 7.74 ms; 16-spp batches want the full grid: 327 vs 302 Msamples/s)
         const uint32_t waves = (c->n_sets >= 2 && n_paths <= (4u << 20)) ? std::max(256u, c->extend_waves / 2u) : c->extend_waves;
-        if (fresh && s0 == 0 && c->last_resolved) HIP_TRY(c, hipStreamWaitEvent(st, c->last_resolved, 0));
         EventPair whole{};
         if (c->profiling) { whole = get_events(c, 2); HIP_TRY(c, hipEventRecord(whole.a, st)); }
         f.mean_base = u->accumulated_count + s0;
@@ -856,11 +855,14 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
                 HIP_TRY(c, hipEventRecord(e.b, st)); c->events.push_back(e);
                 e2 = get_events(c, 1); HIP_TRY(c, hipEventRecord(e2.a, st));
             }
+            if (b == 0 && c->last_first_shade && c->last_first_shade != ps.first_shade)
+                HIP_TRY(c, hipStreamWaitEvent(st, c->last_first_shade, 0));
             if (!lit) {
                 launch_shade(st, sc, f, img, b, rin, ps.d_hits, ps.d_counters, n_paths, rout, ps.d_results);
             } else {
                 launch_shade_lit(st, sc, f, img, b, rin, ps.d_hits, ps.d_counters, n_paths, rout, shadow_q, ps.d_results);
             }
+            if (b == 0) { HIP_TRY(c, hipEventRecord(ps.first_shade, st)); c->last_first_shade = ps.first_shade; }
             if (c->profiling) { HIP_TRY(c, hipEventRecord(e2.b, st)); c->events.push_back(e2); }
             if (lit && c->n_lights) {
                 // occlusion rays of this bounce: any-hit traversal, then the unoccluded contributions join the radiance

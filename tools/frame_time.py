@@ -45,4 +45,14 @@ for prof in (0, 1):
     if prof:
         out[key].update(extend_ms_per_frame=round(st["extend_ms"] / frames, 3), shade_ms_per_frame=round(st["shade_ms"] / frames, 3),
                         gpu_ms_per_frame=round(st["total_ms"] / frames, 3))
+# a moving camera: every frame restarts the accumulation (renderer.rs:988-1000) and rewrites the G-buffers
+ctx.set_profiling(0)
+ctx.reset_stats()
+t = time.perf_counter()
+for k in range(frames):
+    r.set_camera(wl["pos"], host.yaw_quat(wl["yaw"] + 0.05 * (k + 1)), np.deg2rad(np.float32(wl["fov"])), 0.1, 1000.0)
+    r.record_commands()
+ctx.synchronize()
+dt = time.perf_counter() - t
+out["moving_camera"] = {"ms_per_frame": round(dt * 1e3 / frames, 3)}
 print(json.dumps(out))
