@@ -556,7 +556,14 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
         same_list = inst[i].geometry == c->built_instances[i].geometry && memcmp(&inst[i].off, &c->built_instances[i].off, sizeof(ptx_offsets)) == 0;
     // on the device when nothing else has to change (an emitter that moves takes the light table with it: host path)
     const bool host_refit_only = getenv("PTX_HOST_REFIT") != nullptr;
-    if (same_list && c->refit_ready && c->n_lights == 0 && !host_refit_only && c->bvh.level_first.size() >= 2) {
+    bool emitter_moved = false;
+    if (same_list && c->n_lights)
+        for (uint32_t i = 0; i < n && !emitter_moved; ++i) {
+            const ptx_material_ext &e = c->material_ext[inst[i].off.material_offset];
+            if ((e.emissive[0] > 0.0f || e.emissive[1] > 0.0f || e.emissive[2] > 0.0f) &&
+                memcmp(inst[i].xform, c->built_instances[i].xform, sizeof inst[i].xform) != 0) emitter_moved = true;
+        }
+    if (same_list && c->refit_ready && !emitter_moved && !host_refit_only && c->bvh.level_first.size() >= 2) {
         bool ok = false;
         if (int r = device_refit(c, inst, n, ok)) return r;
         lap("dev refit");

@@ -183,3 +183,42 @@ def test_host_lit_matches_oracle(oracle):
     want = sc.render(cam_cornell(oracle), 96, 96, 4, SEED, params=oracle.default_params(max_depth=8, integrator=oracle.INTEGRATOR_LIT))
     assert_images_bit_equal(got, want, "host lit cornell")
     r.close()
+
+
+def test_lit_scene_motion_device_refit_and_moving_emitter(oracle, monkeypatch):
+    """Lit scene + instance motion: moving the tall box refits on the GPU (the light table is untouched), moving the
+    emitter takes the host path (the light table follows it); both equal the oracle's render of the moved scene."""
+    import os
+    from helpers import ASSETS
+    from path_tracer_amd import capi, host
+    monkeypatch.setenv("PTX_REFIT_VERIFY", "1")
+    r = host.Renderer(80, 80, 0)
+    r.set_ref_quirks(False)
+    r.import_gltf(os.path.join(ASSETS, "cornell_lit", "cornell_lit.gltf"))
+    fov = np.deg2rad(np.float32(40.0))
+    r.set_camera([0.0, 1.0, 3.9], host.yaw_quat(0.0), fov, 0.1, 1000.0)
+    r.set_seed(SEED, fixed=True)
+    r.set_params(capi.default_params(max_depth=6, integrator=capi.INTEGRATOR_LIT))
+    r.record_commands(); r.record_commands()
+    ing = cornell_lit()
+    cam = cam_cornell(oracle)
+    opts = oracle.SCENE_WORLD_NORMALS | oracle.SCENE_TEXTURE_TIMES_FACTOR
+
+    def move(entity, dpos):
+        geom, (p, q, s), mat = ing.entities[entity]
+        ing.entities[entity] = (geom, (p + np.float32(dpos), q, s), mat)
+        r.set_entity_transform(entity, p + np.float32(dpos), q, s)
+        r.record_commands()
+        r.record_commands_batch(3)
+        got = {k: r.read_image(v) for k, v in (("albedo", capi.IMAGE_ALBEDO), ("normal", capi.IMAGE_NORMAL),
+                                               ("depth", capi.IMAGE_DEPTH), ("ids", capi.IMAGE_PRIMARY_ID))}
+        sc = oracle.scene_from_ingest(ing, options=opts, with_material_ext=True)
+        want = sc.render(cam, 80, 80, 3, SEED, params=oracle.default_params(max_depth=6, integrator=oracle.INTEGRATOR_LIT))
+        assert_images_bit_equal(got, want, "lit cornell after moving entity %d" % entity)
+        return r.stats()
+
+    st = move(7, [0.15, 0.0, 0.2])          # tall box (metal): device refit
+    assert st["bvh_refits"] == 1 and st["bvh_device_refits"] == 1 and st["bvh_builds"] == 1
+    st = move(4, [0.2, -0.05, 0.1])         # the light quad: host refit, new light table
+    assert st["bvh_refits"] == 2 and st["bvh_device_refits"] == 1 and st["bvh_builds"] == 1
+    r.close()
