@@ -857,7 +857,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
             uint64_t *trav = c->count_traversal ? c->d_totals + 3 : nullptr;
             EventPair e{}, e2{};
             if (c->profiling) { e = get_events(c, 0); HIP_TRY(c, hipEventRecord(e.a, st)); }
-            launch_extend(st, sc, f, rin, ps.d_counters + b, ps.d_counters + kNextBase + b, n_paths, waves, ps.d_hits, trav);
+            launch_extend(st, sc, f, rin, ps.d_counters + b, ps.d_counters + kNextBase + b, n_paths, waves, ps.d_hits, trav, false, b == 0);
             if (c->profiling) {
                 HIP_TRY(c, hipEventRecord(e.b, st)); c->events.push_back(e);
                 e2 = get_events(c, 1); HIP_TRY(c, hipEventRecord(e2.a, st));

@@ -120,7 +120,7 @@ void launch_raygen(hipStream_t s, const FrameDev &f, uint32_t n_paths, RayQueue 
 // `next`: the bounce's fetch cursor (zeroed by raygen); `max_waves`: resident-wave budget of the persistent grid
 void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, RayQueue rays, const uint32_t *count,
                    uint32_t *next, uint32_t capacity, uint32_t max_waves, HitOut *hits,
-                   uint64_t *trav_totals /* NULL: uninstrumented */, bool any_hit = false);
+                   uint64_t *trav_totals /* NULL: uninstrumented */, bool any_hit = false, bool primary = false);
 uint32_t extend_resident_waves(int device);
 void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
                   RayQueue rays_in, const HitOut *hits, uint32_t *counters, uint32_t capacity, RayQueue rays_out,

@@ -114,7 +114,7 @@ struct LaneStack {
 };
 
 // wave-uniform scheduling thresholds (lane counts) and the ray-fetch chunk
-struct ExtendSched { int refill, tri_min, flush_min; uint32_t chunk; };
+struct ExtendSched { int refill, tri_min, flush_min; uint32_t chunk, chunk_grow; };
 
 #ifndef PTX_EXTEND_WAVES_PER_EU
 #define PTX_EXTEND_WAVES_PER_EU 7
@@ -185,7 +185,16 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
     unsigned long long tot_nodes = 0, tot_tris = 0;
     unsigned long long w_iters = 0, w_node_blocks = 0, w_node_lanes = 0, w_tri_blocks = 0, w_tri_lanes = 0, w_refills = 0;
     uint32_t chunk_next = 0, chunk_end = 0;
-    const uint32_t chunk = sched.chunk;
+    // Rays are handed out in chunks, one atomic each.  A single word takes ~88 M atomics/s, so a long queue of cheap
+    // rays (33 M primary rays that mostly miss: 260 k chunks of 128) is bound by that rate alone -- 3.1 ms measured
+    // where the rays themselves need 1 ms; a short queue wants small chunks to keep the waves balanced.  Hence the
+    // chunk grows with the queue of camera rays: about 8 chunks per wave, between sched.chunk (128) and 4 x sched.chunk.
+    uint32_t chunk = sched.chunk;
+    {
+        const uint32_t per_wave = n / (gridDim.x * 8u);
+        const uint32_t cap = sched.chunk * sched.chunk_grow;
+        if (per_wave > chunk) chunk = (per_wave < cap ? per_wave : cap) & ~63u;
+    }
     // wave-uniform: the queue has been handed out completely.  At most ceil(n / chunk) waves can ever
     // receive rays: on a short queue (late bounces, small frames) the rest of the grid starts out
     // "exhausted" and leaves without paying a same-address atomic (~88 M/s chip-wide).
@@ -856,15 +865,20 @@ static const ExtendSched &extend_sched()
         auto knob = [](const char *name, int dflt) { const char *e = getenv(name); int v = e ? atoi(e) : dflt; return v < 1 ? 1 : (v > 64 ? 64 : v); };
         ExtendSched k; k.refill = knob("PTX_REFILL", 8); k.tri_min = knob("PTX_TRI_MIN", 64); k.flush_min = knob("PTX_FLUSH_MIN", 8);
         const char *ce = getenv("PTX_CHUNK"); int cv = ce ? atoi(ce) : 128; k.chunk = (uint32_t)(cv < 64 ? 64 : cv);
+        k.chunk_grow = (uint32_t)knob("PTX_CHUNK_GROW", 4);
         return k;
     }();
     return sched;
 }
 
 void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, RayQueue rays, const uint32_t *count,
-                   uint32_t *next, uint32_t capacity, uint32_t max_waves, HitOut *hits, uint64_t *trav_totals, bool any_hit)
+                   uint32_t *next, uint32_t capacity, uint32_t max_waves, HitOut *hits, uint64_t *trav_totals, bool any_hit,
+                   bool primary)
 {
-    const ExtendSched &sched = extend_sched();
+    ExtendSched sched = extend_sched();
+    // only the camera rays form long queues of cheap, uniform rays; later bounces keep the small chunk (their rays are
+    // heavy-tailed and a large chunk lengthens the kernel's tail: Sponza 16-spp batches lose 0.7 % with it)
+    if (!primary) sched.chunk_grow = 1;
     uint32_t blocks = std::min((capacity + kExtendBlock - 1u) / kExtendBlock, max_waves);
     if (!blocks) return;
     unsigned long long *tt = reinterpret_cast<unsigned long long *>(trav_totals);
