@@ -378,23 +378,25 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
     __shared__ uint32_t s_wave_live[kShadeBlock / 64], s_wave_hits[kShadeBlock / 64];
     __shared__ uint32_t s_base;
 
-    // Every fetch that does not depend on another is issued before the first wait: the ray, its
-    // hit and the live count together, then the triangle's record, while the sRGB table and the
-    // texture descriptors go to LDS.
-    const uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x;
-    if (blockIdx.x * kShadeBlock >= counters[depth]) return;      // the grid covers the chunk's capacity, the queue may be far shorter
-    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
-    float2 hr = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
-    if (i < capacity) {
-        r0 = rays_in.org[i]; r1 = rays_in.dir[i]; r2 = rays_in.thr[i];
-        hr = *reinterpret_cast<const float2 *>(hits + i);
-    }
+    // The grid is capped (launch_shade): a block walks tiles of kShadeBlock rays until the live queue ends, so a
+    // launch over a nearly empty queue (late bounces) costs a few thousand block starts, not capacity / 512 of them.
     const uint32_t n_live = counters[depth];
+    if ((uint64_t)blockIdx.x * kShadeBlock >= n_live) return;
     if (threadIdx.x < 256) s_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];
     {
         const uint32_t nw = (sc.n_textures < kLdsTextures ? sc.n_textures : kLdsTextures) * (uint32_t)(sizeof(TexDesc) / 4);
         for (uint32_t w = threadIdx.x; w < nw; w += kShadeBlock)
             reinterpret_cast<uint32_t *>(s_tex)[w] = reinterpret_cast<const uint32_t *>(sc.textures)[w];
+    }
+    for (uint32_t tile = blockIdx.x; (uint64_t)tile * kShadeBlock < n_live; tile += gridDim.x) {
+    // Every fetch that does not depend on another is issued before the first wait: the ray and its
+    // hit together, then the triangle's record.
+    const uint32_t i = tile * kShadeBlock + threadIdx.x;
+    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
+    float2 hr = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
+    if (i < capacity) {
+        r0 = rays_in.org[i]; r1 = rays_in.dir[i]; r2 = rays_in.thr[i];
+        hr = *reinterpret_cast<const float2 *>(hits + i);
     }
     const bool valid = i < capacity && i < n_live;
     const uint32_t tri = valid ? __float_as_uint(hr.y) : 0xFFFFFFFFu;
@@ -520,6 +522,8 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
         uint32_t before = wave ? s_wave_live[wave - 1] : 0u;
         uint32_t slot = s_base + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
         rays_out.org[slot] = o0; rays_out.dir[slot] = o1; rays_out.thr[slot] = o2; rays_out.inv[slot] = o3;
+    }
+    __syncthreads();      // the LDS scan words are reused by the next tile
     }
 }
 
@@ -901,6 +905,8 @@ void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const Im
 {
     uint32_t blocks = (capacity + kShadeBlock - 1u) / kShadeBlock;
     if (!blocks) return;
+    static const uint32_t cap = [] { const char *e = getenv("PTX_SHADE_GRID"); int v = e ? atoi(e) : 8192; return (uint32_t)(v < 64 ? 64 : v); }();
+    blocks = std::min(blocks, cap);
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kShadeBlock), 0, s, sc, f, img, depth, rays_in, hits, counters,
                        capacity, rays_out, results);
 }
