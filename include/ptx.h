@@ -115,9 +115,12 @@ typedef enum {
 } ptx_scene_option;
 
 /* ptx_add_texture `srgb` argument as a flag word: bit0 sRGB decode, bit1 wrap = repeat instead of the
- * reference's clamp-to-edge (graphics.rs:446-459 reads the glTF sampler and then ignores it). */
+ * reference's clamp-to-edge, bit2 bilinear instead of the reference's nearest filter (graphics.rs:446-459
+ * reads the glTF sampler's wrap and filter modes and then ignores them).  Bilinear: LOD 0, texel centres at
+ * i + 0.5, the four texels decoded (sRGB -> linear) before the blend, neighbours wrapped / clamped per bit1. */
 #define PTX_TEXTURE_SRGB 1
 #define PTX_TEXTURE_REPEAT 2
+#define PTX_TEXTURE_LINEAR 4
 
 /* Fixed buffer capacities; defaults are the reference's (scene/mod.rs:48-54, renderer.rs:180). */
 typedef struct {

@@ -254,6 +254,9 @@ class IngestedScene:
                 if samp.get("wrapS", 10497) == 10497 and samp.get("wrapT", 10497) == 10497:
                     flags |= 2                                                   # wrap = repeat (glTF default)
                     ident += "#repeat"
+                if samp.get("magFilter", 9729) == 9729:
+                    flags |= 4                                                   # LINEAR (also when the sampler leaves it open)
+                    ident += "#linear"
             if ident not in self.texture_lookup:                                 # graphics.rs:396-398
                 rgba = np.asarray((decode_image or decode_image_pil)(os.path.join(base, image["uri"])), np.uint8)
                 if rgba.shape[2] == 3:                                            # graphics.rs:507-516

@@ -568,20 +568,63 @@ static void miss_shader(payload_t *pl, v3 ray_dir)
     pl->normal = v3_make(0.0f, 0.0f, 0.0f);
 }
 
+/* one texel, decoded the way the hardware's R8G8B8A8_SRGB / _UNORM fetch does */
+static inline v3 texel_at(const orc_texture *tx, uint32_t x, uint32_t y)
+{
+    const uint8_t *px = tx->rgba8 + ((uint64_t)y * tx->width + x) * 4;
+    if (tx->srgb & 1u) return v3_make(g_srgb_lut[px[0]], g_srgb_lut[px[1]], g_srgb_lut[px[2]]);
+    return v3_make((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+}
+
+/* build extension (flag bit 2, glTF magFilter LINEAR, graphics.rs:446-451 reads it and drops it): bilinear
+ * filter at LOD 0 in the Vulkan convention -- texel centres at i + 0.5, weights from the fraction of
+ * u*W - 0.5, the four texels decoded to linear before the blend; neighbours wrap or clamp like the texel itself */
+static inline void linear_axis(float u, uint32_t size, int repeat, uint32_t *i0, uint32_t *i1, float *a)
+{
+    float x = u * (float)size - 0.5f;
+    float xf = floorf(x);
+    float fr = x - xf;
+    if (!(fr >= 0.0f)) fr = 0.0f;
+    if (fr > 1.0f) fr = 1.0f;
+    float hi = (float)size;
+    if (!(xf >= -1.0f)) xf = -1.0f;
+    if (xf > hi) xf = hi;
+    int32_t k0 = (int32_t)xf, k1 = k0 + 1, n = (int32_t)size;
+    if (repeat) {
+        if (k0 < 0) k0 += n;
+        if (k0 >= n) k0 -= n;
+        if (k1 >= n) k1 -= n;
+        if (k1 >= n) k1 -= n;
+    } else {
+        if (k0 < 0) k0 = 0;
+        if (k0 > n - 1) k0 = n - 1;
+        if (k1 > n - 1) k1 = n - 1;
+    }
+    *i0 = (uint32_t)k0; *i1 = (uint32_t)k1; *a = fr;
+}
+
 /* texture(textures[i], uv): vulkano SamplerCreateInfo::default() = nearest, clamp-to-edge,
  * LOD 0 (graphics.rs:453-459, parity unpinned); texel = clamp(floor(u*W),0,W-1) */
 static v3 sample_texture(const orc_texture *tx, float u, float v)
 {
     if (tx->srgb & 2u) { u = u - floorf(u); v = v - floorf(v); }   /* build extension: wrap = repeat */
+    if (tx->srgb & 4u) {
+        uint32_t x0, x1, y0, y1; float ax, ay;
+        linear_axis(u, tx->width, (tx->srgb & 2u) != 0, &x0, &x1, &ax);
+        linear_axis(v, tx->height, (tx->srgb & 2u) != 0, &y0, &y1, &ay);
+        v3 c00 = texel_at(tx, x0, y0), c10 = texel_at(tx, x1, y0), c01 = texel_at(tx, x0, y1), c11 = texel_at(tx, x1, y1);
+        float bx = 1.0f - ax, by = 1.0f - ay;
+        v3 top = v3_add(v3_scale(c00, bx), v3_scale(c10, ax));
+        v3 bot = v3_add(v3_scale(c01, bx), v3_scale(c11, ax));
+        return v3_add(v3_scale(top, by), v3_scale(bot, ay));
+    }
     float fu = floorf(u * (float)tx->width), fv = floorf(v * (float)tx->height);
     float mu = (float)(tx->width - 1), mv = (float)(tx->height - 1);
     if (!(fu >= 0.0f)) fu = 0.0f;
     if (fu > mu) fu = mu;
     if (!(fv >= 0.0f)) fv = 0.0f;
     if (fv > mv) fv = mv;
-    const uint8_t *px = tx->rgba8 + ((uint64_t)(uint32_t)fv * tx->width + (uint32_t)fu) * 4;
-    if (tx->srgb & 1u) return v3_make(g_srgb_lut[px[0]], g_srgb_lut[px[1]], g_srgb_lut[px[2]]);
-    return v3_make((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+    return texel_at(tx, (uint32_t)fu, (uint32_t)fv);
 }
 
 /* rchit.glsl:158-254 */

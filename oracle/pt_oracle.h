@@ -73,7 +73,8 @@ typedef struct {
     const uint8_t *rgba8;   /* W*H*4, row 0 first */
     uint32_t width, height;
     uint32_t srgb;          /* bit0: R8G8B8A8_SRGB (graphics.rs:494-495); bit1 (build extension):
-                               wrap = repeat instead of the reference's clamp-to-edge */
+                               wrap = repeat instead of the reference's clamp-to-edge; bit2 (same): bilinear filter
+                               instead of nearest */
     uint32_t _pad;
 } orc_texture;
 

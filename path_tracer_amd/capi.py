@@ -14,7 +14,7 @@ PTX_OK, PTX_ERR_INVALID, PTX_ERR_CAPACITY, PTX_ERR_HIP, PTX_ERR_STATE = range(5)
 IMAGE_ALBEDO, IMAGE_NORMAL, IMAGE_DEPTH, IMAGE_PRIMARY_ID = range(4)
 INTEGRATOR_REFERENCE, INTEGRATOR_LIT = 0, 1
 SCENE_WORLD_NORMALS, SCENE_TEXTURE_TIMES_FACTOR = 1, 2
-TEXTURE_SRGB, TEXTURE_REPEAT = 1, 2
+TEXTURE_SRGB, TEXTURE_REPEAT, TEXTURE_LINEAR = 1, 2, 4
 
 VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("_p0", "<f4"), ("normal", "<f4", 3), ("_p1", "<f4"),
                          ("uv", "<f4", 2), ("padding", "<f4", 2)])
@@ -176,7 +176,7 @@ class Context:
         return out.value
 
     def add_texture(self, rgba8, srgb=True):
-        """`srgb`: bool, or the flag word TEXTURE_SRGB | TEXTURE_REPEAT."""
+        """`srgb`: bool, or the flag word TEXTURE_SRGB | TEXTURE_REPEAT | TEXTURE_LINEAR."""
         a = np.ascontiguousarray(rgba8, dtype=np.uint8)
         assert a.ndim == 3 and a.shape[2] == 4
         out = C.c_uint32()

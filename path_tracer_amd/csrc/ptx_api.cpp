@@ -408,7 +408,7 @@ int ptx_add_texture(ptx_context *c, const uint8_t *rgba8, uint32_t w, uint32_t h
 {
     if (!c) return PTX_ERR_INVALID;
     if (!rgba8 || !index || w == 0 || h == 0) return fail(c, PTX_ERR_INVALID, "ptx_add_texture: bad argument");
-    if (srgb & ~(PTX_TEXTURE_SRGB | PTX_TEXTURE_REPEAT)) return fail(c, PTX_ERR_INVALID, "ptx_add_texture: unknown flag bit");
+    if (srgb & ~(PTX_TEXTURE_SRGB | PTX_TEXTURE_REPEAT | PTX_TEXTURE_LINEAR)) return fail(c, PTX_ERR_INVALID, "ptx_add_texture: unknown flag bit");
     if (c->textures.size() + 1 > c->limits.max_textures)
         return fail(c, PTX_ERR_CAPACITY, "ptx_add_texture: bindless texture pool size exceeded"); // renderer.rs:899-901
     if (int r = bind(c)) return r;
@@ -418,7 +418,7 @@ int ptx_add_texture(ptx_context *c, const uint8_t *rgba8, uint32_t w, uint32_t h
     hipError_t e = hipMemcpy(d, rgba8, bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d); return fail(c, PTX_ERR_HIP, std::string("ptx_add_texture: ") + hipGetErrorString(e)); }
     TexDesc t; t.texels = (const uint8_t *)d; t.width = w; t.height = h; t._pad = 0;
-    t.srgb = (uint32_t)srgb & (uint32_t)(PTX_TEXTURE_SRGB | PTX_TEXTURE_REPEAT);
+    t.srgb = (uint32_t)srgb & (uint32_t)(PTX_TEXTURE_SRGB | PTX_TEXTURE_REPEAT | PTX_TEXTURE_LINEAR);
     *index = (uint32_t)c->textures.size();
     c->textures.push_back(t);
     c->textures_dirty = true;

@@ -348,20 +348,60 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
 }
 
 // ---------------------------------------------------------------- shade
+__device__ __forceinline__ f3 texel_at(const TexDesc &tx, const float *lut, uint32_t x, uint32_t y)
+{
+    uint32_t texel = *reinterpret_cast<const uint32_t *>(tx.texels + ((uint64_t)y * tx.width + x) * 4u);
+    uint32_t r = texel & 0xFFu, g = (texel >> 8) & 0xFFu, b = (texel >> 16) & 0xFFu;
+    if (tx.srgb & 1u) return mk3(lut[r], lut[g], lut[b]);
+    return mk3((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f);
+}
+
+// PTX_TEXTURE_LINEAR: texel centres at i + 0.5; the pair of texels and the blend weight along one axis
+__device__ __forceinline__ void linear_axis(float u, uint32_t size, bool repeat, uint32_t &i0, uint32_t &i1, float &a)
+{
+    float x = u * (float)size - 0.5f;
+    float xf = floorf(x);
+    float fr = x - xf;
+    if (!(fr >= 0.0f)) fr = 0.0f;
+    if (fr > 1.0f) fr = 1.0f;
+    float hi = (float)size;
+    if (!(xf >= -1.0f)) xf = -1.0f;
+    if (xf > hi) xf = hi;
+    int32_t k0 = (int32_t)xf, k1 = k0 + 1, n = (int32_t)size;
+    if (repeat) {
+        if (k0 < 0) k0 += n;
+        if (k0 >= n) k0 -= n;
+        if (k1 >= n) k1 -= n;
+        if (k1 >= n) k1 -= n;
+    } else {
+        if (k0 < 0) k0 = 0;
+        if (k0 > n - 1) k0 = n - 1;
+        if (k1 > n - 1) k1 = n - 1;
+    }
+    i0 = (uint32_t)k0; i1 = (uint32_t)k1; a = fr;
+}
+
 __device__ __forceinline__ f3 sample_texture(const TexDesc &tx, const float *lut, float u, float v)
 {
     // vulkano SamplerCreateInfo::default(): nearest, clamp-to-edge, LOD 0 (graphics.rs:453-459)
     if (tx.srgb & 2u) { u = u - floorf(u); v = v - floorf(v); }   // build extension: wrap = repeat
+    if (tx.srgb & 4u) {                                           // build extension: bilinear, blended after the sRGB decode
+        uint32_t x0, x1, y0, y1; float ax, ay;
+        linear_axis(u, tx.width, (tx.srgb & 2u) != 0u, x0, x1, ax);
+        linear_axis(v, tx.height, (tx.srgb & 2u) != 0u, y0, y1, ay);
+        f3 c00 = texel_at(tx, lut, x0, y0), c10 = texel_at(tx, lut, x1, y0), c01 = texel_at(tx, lut, x0, y1), c11 = texel_at(tx, lut, x1, y1);
+        float bx = 1.0f - ax, by = 1.0f - ay;
+        f3 top = c00 * bx + c10 * ax;
+        f3 bot = c01 * bx + c11 * ax;
+        return top * by + bot * ay;
+    }
     float fu = floorf(u * (float)tx.width), fv = floorf(v * (float)tx.height);
     float mu = (float)(tx.width - 1u), mv = (float)(tx.height - 1u);
     if (!(fu >= 0.0f)) fu = 0.0f;
     if (fu > mu) fu = mu;
     if (!(fv >= 0.0f)) fv = 0.0f;
     if (fv > mv) fv = mv;
-    uint32_t texel = *reinterpret_cast<const uint32_t *>(tx.texels + ((uint64_t)(uint32_t)fv * tx.width + (uint32_t)fu) * 4u);
-    uint32_t r = texel & 0xFFu, g = (texel >> 8) & 0xFFu, b = (texel >> 16) & 0xFFu;
-    if (tx.srgb & 1u) return mk3(lut[r], lut[g], lut[b]);
-    return mk3((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f);
+    return texel_at(tx, lut, (uint32_t)fu, (uint32_t)fv);
 }
 
 #ifdef PTX_SHADE_WAVES

@@ -51,10 +51,10 @@ const Texture *Renderer::lookup_texture(const std::string &ident) const
     return it == loaded_textures_map_.end() ? nullptr : &it->second;
 }
 
-uint32_t Renderer::add_texture(const uint8_t *rgba8, uint32_t w, uint32_t h, bool srgb, bool repeat)
+uint32_t Renderer::add_texture(const uint8_t *rgba8, uint32_t w, uint32_t h, bool srgb, bool repeat, bool linear)
 {
     uint32_t idx = 0;
-    int flags = (srgb ? PTX_TEXTURE_SRGB : 0) | (repeat ? PTX_TEXTURE_REPEAT : 0);
+    int flags = (srgb ? PTX_TEXTURE_SRGB : 0) | (repeat ? PTX_TEXTURE_REPEAT : 0) | (linear ? PTX_TEXTURE_LINEAR : 0);
     if (ptx_add_texture(ctx_, rgba8, w, h, flags, &idx)) ptx_throw(ctx_, "Bindless texture pool size exceeded");
     return idx;
 }

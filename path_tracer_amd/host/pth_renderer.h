@@ -31,7 +31,7 @@ public:
     // renderer.rs:867-904
     const Texture *lookup_texture(const std::string &ident) const;
     void add_texture_to_lookup_map(const std::string &ident, const Texture &t) { loaded_textures_map_[ident] = t; }
-    uint32_t add_texture(const uint8_t *rgba8, uint32_t w, uint32_t h, bool srgb, bool repeat = false);
+    uint32_t add_texture(const uint8_t *rgba8, uint32_t w, uint32_t h, bool srgb, bool repeat = false, bool linear = false);
 
     // Build extension (the --no-ref-quirks switch; default true = the reference's behaviour).
     // false: normals go to world space, texels are multiplied by baseColorFactor, import_gltf descends into

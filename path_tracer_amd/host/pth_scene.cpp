@@ -114,15 +114,19 @@ Material material_from_gltf(const Json &doc, const Json *gltf_mat, Renderer &ren
             // graphics.rs:446-451 reads the glTF sampler's wrap / filter modes and then builds a default
             // sampler (clamp-to-edge, todo.md:6).  Without the reference's quirks the wrap mode is honoured
             // (glTF default: repeat, 10497).
-            bool repeat = false;
+            // and so is the magnification filter (LINEAR = 9729, also when the sampler leaves it open).
+            bool repeat = false, linear = false;
             if (!renderer.ref_quirks()) {
-                int64_t ws = 10497, wt = 10497;
+                int64_t ws = 10497, wt = 10497, mag = 9729;
                 if (tex.has("sampler")) {
                     const Json &smp = doc.at("samplers").at((size_t)tex.get_int("sampler", 0));
                     ws = smp.get_int("wrapS", 10497); wt = smp.get_int("wrapT", 10497);
+                    mag = smp.get_int("magFilter", 9729);
                 }
                 repeat = ws == 10497 && wt == 10497;
                 if (repeat) ident += "#repeat";
+                linear = mag == 9729;
+                if (linear) ident += "#linear";
             }
             // gltf::image::Data::from_source decodes on every call (material.rs:64-65); the
             // renderer's ident cache then skips the upload (graphics.rs:396-398).  Decoding is
@@ -142,7 +146,7 @@ Material material_from_gltf(const Json &doc, const Json *gltf_mat, Renderer &ren
                     }
                     px = rgba.data();
                 }
-                t.bindless_indice = renderer.add_texture(px, img.width, img.height, true, repeat);   // R8G8B8A8_SRGB
+                t.bindless_indice = renderer.add_texture(px, img.width, img.height, true, repeat, linear);   // R8G8B8A8_SRGB
                 renderer.add_texture_to_lookup_map(ident, t);
             }
             m.has_base_texture = true;

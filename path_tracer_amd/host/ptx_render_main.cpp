@@ -38,7 +38,7 @@ void usage()
             "  --gpus N         GPUs, samples split evenly (1)\n"
             "  --out PREFIX     output prefix (render); existing files are not overwritten\n"
             "  --no-pfm         write only the PNG\n"
-            "  --no-ref-quirks  world-space normals, texel x baseColorFactor, child nodes, sampler wrap modes\n"
+            "  --no-ref-quirks  world-space normals, texel x baseColorFactor, child nodes, sampler wrap + filter\n"
             "  --lit            lit integrator (emissive triangles + next-event estimation + GGX / glass); implies --no-ref-quirks\n");
 }
 

@@ -91,10 +91,12 @@ def test_world_normals_option_reference_integrator(oracle, gpu_ctx_factory):
 
 def test_textured_lit_and_texture_options(oracle, gpu_ctx_factory):
     """lion + boulder (2k textures, no emitters: sky light only) through the lit integrator, with texel x
-    factor; and the stress scene's 70 textures with wrap = repeat on the odd ones, reference integrator."""
+    factor and bilinear filtering; and the stress scene's 70 textures with every wrap / filter combination,
+    reference integrator."""
     from path_tracer_amd import capi
     opts = capi.SCENE_WORLD_NORMALS | capi.SCENE_TEXTURE_TIMES_FACTOR
     ing = lion_boulder()
+    ing.textures = [(rgba, flags | capi.TEXTURE_LINEAR) for rgba, flags in ing.textures]      # 2k textures, bilinear
     ctx = gpu_ctx_factory()
     upload(ctx, ing, oracle, options=opts, with_material_ext=True)
     sc = oracle.scene_from_ingest(ing, options=opts, with_material_ext=True)
@@ -105,7 +107,8 @@ def test_textured_lit_and_texture_options(oracle, gpu_ctx_factory):
     assert want["stats"]["textured_hits"] > 0 and want["stats"]["shadow_rays"] == 0
 
     ing = stress_scene()
-    ing.textures = [(rgba, flags | (2 if i % 2 else 0)) for i, (rgba, flags) in enumerate(ing.textures)]
+    # wrap = repeat on the odd ones, bilinear on two of three: all four sampler combinations, sRGB and linear texels
+    ing.textures = [(rgba, flags | (2 if i % 2 else 0) | (4 if i % 3 else 0)) for i, (rgba, flags) in enumerate(ing.textures)]
     ctx = gpu_ctx_factory()
     upload(ctx, ing, oracle, options=capi.SCENE_TEXTURE_TIMES_FACTOR)
     sc = oracle.scene_from_ingest(ing, options=oracle.SCENE_TEXTURE_TIMES_FACTOR)

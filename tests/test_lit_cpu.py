@@ -174,3 +174,62 @@ def test_texture_wrap_repeat_and_factor(oracle):
         np.testing.assert_allclose(fac, [0.5, 0, 0], atol=1e-6)
     else:
         raise AssertionError("sample absorbed at the probe pixel; pick another")
+
+
+def test_texture_bilinear_filter(oracle):
+    """A 4-texel ramp across a quad seen head-on: nearest gives steps, bilinear (flag 4) reproduces the ramp
+    between texel centres, holds the edge texel under clamp and blends across the seam under repeat."""
+    from oracle.gltf_ingest import IngestedScene, MATERIAL_DTYPE, VERTEX_DTYPE
+    tex = np.zeros((1, 4, 4), np.uint8)
+    tex[0, :, 0] = [0, 85, 170, 255]; tex[0, :, 1] = [255, 170, 85, 0]; tex[0, :, 3] = 255
+
+    def scene(flags):
+        ing = IngestedScene()
+        ing.textures.append((tex, flags))
+        m = np.zeros(1, dtype=MATERIAL_DTYPE)
+        m["base_color"] = [1, 1, 1, 1]; m["has_base_texture"] = 1; m["roughness"] = 1.0
+        mi = ing.add_material(m)
+        v = np.zeros(4, dtype=VERTEX_DTYPE)
+        v["position"] = [[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]]
+        v["normal"] = [[0, 0, 1]] * 4
+        v["uv"] = [[0, 1], [1, 1], [1, 0], [0, 0]]
+        geom = ing._geometry_create("quad", v, np.uint32([0, 1, 2, 0, 2, 3]))
+        ing.entities.append((geom, (np.float32([0, 0, 0]), np.float32([0, 0, 0, 1]), np.float32([1, 1, 1])), mi))
+        return oracle.scene_from_ingest(ing)
+
+    W = 96
+    cam = oracle.camera_matrices([0, 0, 2.0], oracle.yaw_quat(0), np.deg2rad(np.float32(60)), 1.0, 0.1, 1000.0)
+    px = np.arange(W)
+    world_x = ((px + 0.5) / W * 2 - 1) * np.tan(np.deg2rad(30.0)) * 2.0
+    u = (world_x + 1) / 2
+    inside = (u > 0.01) & (u < 0.99)
+
+    def row(flags):
+        r = scene(flags).render(cam, W, W, 1, SEED, params=oracle.default_params(max_depth=1))
+        a = r["albedo"][W // 2, :, :3]
+        assert (r["ids"][W // 2, inside, 0] == 0).all()
+        return a, a.sum(axis=1) > 0            # (an absorbed sample is black)
+
+    x = u * 4 - 0.5
+    near, ok = row(0)
+    want_near = np.clip(np.floor(u * 4), 0, 3) / 3
+    sel = inside & ok
+    np.testing.assert_allclose(near[sel, 0], want_near[sel], atol=1e-6)
+    lin, ok = row(4)
+    sel = inside & ok
+    np.testing.assert_allclose(lin[sel, 0], np.clip(x, 0, 3)[sel] / 3, atol=1e-5)
+    np.testing.assert_allclose(lin[sel, 1], 1 - np.clip(x, 0, 3)[sel] / 3, atol=1e-5)
+    rep, ok = row(4 | 2)
+    sel = inside & ok
+    xr = np.where(x < 0, x + 4, x)                       # texel -1 is texel 3 under repeat
+    i0 = np.floor(xr).astype(int) % 4
+    fr = xr - np.floor(xr)
+    ramp = np.array([0, 1, 2, 3]) / 3
+    want = ramp[i0] * (1 - fr) + ramp[(i0 + 1) % 4] * fr
+    np.testing.assert_allclose(rep[sel, 0], want[sel], atol=1e-5)
+    assert np.abs(rep[sel, 0] - lin[sel, 0]).max() > 0.3  # the seam differs from the clamped edge
+    srgb, ok = row(4 | 1)                                # decoded before the blend
+    sel = inside & ok
+    lut = np.array([oracle.lib().orc_srgb_to_linear(c) for c in (0, 85, 170, 255)])
+    xc = np.clip(x, 0, 3); j = np.minimum(np.floor(xc).astype(int), 2); f = xc - j
+    np.testing.assert_allclose(srgb[sel, 0], (lut[j] * (1 - f) + lut[j + 1] * f)[sel], atol=1e-5)
