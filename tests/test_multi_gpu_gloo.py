@@ -60,3 +60,55 @@ def test_two_rank_spp_partition_matches_single_process(oracle, tmp_path):
     # same samples, different fp32 summation order (running mean vs mean of partial means)
     assert np.abs(combined - whole).max() < 2e-6
     assert rel_mse(combined, whole) < 1e-10
+
+
+def _preview_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as O
+    from path_tracer_amd.multi_gpu import ProgressivePreview, combine_accumulation, partition_samples, render_progressive
+    first, n = partition_samples(TOTAL_SPP, world, rank)
+    sc = O.scene_from_ingest(cornell())
+    cam = O.camera_matrices([0, 1.0, 3.9], O.yaw_quat(0), np.deg2rad(np.float32(40)), W / H, 0.1, 1000.0)
+    state = {"acc": None, "n": 0}
+
+    def render(k):       # the oracle stands in for ptx_render_batch: k more samples onto the running mean
+        r = sc.render(cam, W, H, k, SEED, first_sample=state["n"], params=O.default_params(rng_sample_offset=first),
+                      threads=2, albedo=state["acc"])
+        state["acc"], state["n"] = r["albedo"], state["n"] + k
+
+    previews = []
+    pv = ProgressivePreview(dist, world, root=0, on_preview=lambda img, samples: previews.append((samples, img.numpy().copy())))
+    render_progressive(render, lambda: torch.from_numpy(state["acc"].copy()), n, 1, pv)
+    assert state["n"] == n and pv.submitted == n - 1
+    combined = combine_accumulation(torch.from_numpy(state["acc"].copy()), dist, world, root=0)
+    if rank == 0:
+        assert [s for s, _ in previews] == [world * m for m in range(1, n)], [s for s, _ in previews]
+        np.savez(out_path, final=combined.numpy(), **{"p%d" % s: img for s, img in previews})
+    else:
+        assert previews == [] and pv.latest is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_progressive_preview_two_ranks(tmp_path, oracle):
+    """Previews between chunks equal the mean over the samples both ranks hold at that point, and taking
+    them leaves the final combined image unchanged."""
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "preview.npz")
+    mp.spawn(_preview_worker, args=(world, port, out), nprocs=world, join=True)
+    got = np.load(out)
+    sc = oracle.scene_from_ingest(cornell())
+    cam = oracle.camera_matrices([0, 1.0, 3.9], oracle.yaw_quat(0), np.deg2rad(np.float32(40)), W / H, 0.1, 1000.0)
+    n = TOTAL_SPP // world
+    for m in range(1, n):
+        parts = [sc.render(cam, W, H, m, SEED, params=oracle.default_params(rng_sample_offset=r * n), threads=2)["albedo"] for r in range(world)]
+        want = (parts[0] + parts[1]) * np.float32(0.5)
+        want[..., 3] = 1.0
+        np.testing.assert_array_equal(got["p%d" % (world * m)], want)
+    whole = sc.render(cam, W, H, TOTAL_SPP, SEED, threads=2)["albedo"]
+    assert np.abs(got["final"] - whole).max() < 2e-6
