@@ -199,6 +199,7 @@ struct orc_scene {
     uint64_t *inst_first;        /* first flattened triangle of each instance */
     float (*cof)[9];             /* per instance: cofactor matrix of the 3x3 transform, sign of det folded in */
     light_t *lights; uint64_t n_lights;
+    float *mat_pdf_area;      /* per material: area density of the light pick for a point on a triangle of it */
 };
 
 void orc_default_params(orc_params *p)
@@ -448,7 +449,7 @@ static int light_candidate(const orc_scene *s, const orc_material_ext *e, uint64
 
 static void build_lights(orc_scene *s)
 {
-    s->lights = NULL; s->n_lights = 0;
+    s->lights = NULL; s->n_lights = 0; s->mat_pdf_area = NULL;
     if (!s->d.material_ext) return;
     /* first pass: count and total power (double); second pass: fill */
     uint64_t n = 0, k = 0;
@@ -484,6 +485,15 @@ static void build_lights(orc_scene *s)
     }
     s->lights[li - 1].cdf = 1.0f;
     s->n_lights = li;
+    /* the same density seen from the other side (a BSDF-sampled ray that lands on an emitter): pick probability /
+     * area = luminance / total power, one value per material */
+    s->mat_pdf_area = (float *)calloc(s->d.n_materials ? s->d.n_materials : 1, sizeof(float));
+    for (uint64_t m = 0; m < s->d.n_materials; ++m) {
+        const orc_material_ext *e = &s->d.material_ext[m];
+        if (!(e->emissive[0] > 0.0f || e->emissive[1] > 0.0f || e->emissive[2] > 0.0f)) continue;
+        float lum = (0.2126f * e->emissive[0] + 0.7152f * e->emissive[1]) + 0.0722f * e->emissive[2];
+        s->mat_pdf_area[m] = (float)((double)lum / total);
+    }
 }
 
 uint64_t orc_scene_light_count(const orc_scene *s) { return s->n_lights; }
@@ -542,7 +552,7 @@ orc_scene *orc_scene_create(const orc_scene_desc *desc)
 void orc_scene_destroy(orc_scene *s)
 {
     if (!s) return;
-    free(s->tris); free(s->order); free(s->nodes); free(s->inst_first); free(s->cof); free(s->lights); free(s);
+    free(s->tris); free(s->order); free(s->nodes); free(s->inst_first); free(s->cof); free(s->lights); free(s->mat_pdf_area); free(s);
 }
 
 uint64_t orc_scene_triangle_count(const orc_scene *s) { return s->n_tris; }
@@ -792,11 +802,13 @@ static void raygen_pixel(job_t *j, uint32_t x, uint32_t y)
  * sketch of rchit.glsl:256-265).  NOT a restatement of reference code: the reference has no light
  * sources beyond its sky.  This is the specification the HIP stages k_shade_lit / k_shadow_resolve
  * implement, expression for expression:
- *   - radiance L accumulated per path: sky on a miss, emission when a camera ray or a specular
- *     bounce hits an emitter (emitters reached by a sampled diffuse / glossy bounce are covered by
- *     next-event estimation instead);
+ *   - radiance L accumulated per path: sky on a miss, emission in full when a camera ray or a
+ *     specular bounce hits an emitter;
  *   - next-event estimation at every opaque hit: one emissive triangle picked by area x luminance,
  *     one uniformly sampled point, one occlusion query;
+ *   - multiple importance sampling (power heuristic) between that light sample and the BSDF sample of
+ *     the same vertex: the light sample is weighted by p_l^2 / (p_l^2 + p_b^2), and an emitter reached
+ *     by the sampled diffuse / glossy bounce by p_b^2 / (p_b^2 + p_l^2), both densities per solid angle;
  *   - BSDF: glTF metallic-roughness = Lambert + GGX (VNDF sampling, Smith separable G, Schlick F),
  *     one-sample lobe choice weighted with the mixture pdf; KHR_materials_transmission = smooth
  *     dielectric (Schlick Fresnel, Snell refraction);
@@ -867,6 +879,15 @@ static v3 ggx_sample_vndf(v3 n, v3 wo, float alpha, float u1, float u2)
     return v3_add(v3_add(v3_scale(t, ne.x), v3_scale(b, ne.y)), v3_scale(n, ne.z));
 }
 
+/* power heuristic (beta = 2) of the strategy with density a against the one with density b */
+static inline float lit_mis_weight(float a, float b)
+{
+    float a2 = a * a, b2 = b * b;
+    float w = a2 / (a2 + b2);
+    if (!(w >= 0.0f)) w = 0.0f;
+    return w;
+}
+
 static inline float lit_rand(const float uv[2], uint32_t depth, uint32_t acc, uint32_t seed, uint32_t dim)
 {
     return orc_rand(uv[0], uv[1], depth, acc, seed + dim);
@@ -888,7 +909,7 @@ static void raygen_pixel_lit(job_t *j, uint32_t x, uint32_t y)
     uint64_t pix = (uint64_t)y * W + x;
 
     v3 L = v3_make(0.0f, 0.0f, 0.0f), thr = v3_make(1.0f, 1.0f, 1.0f);
-    int spec = 1;
+    float prev_pdf = 0.0f;      /* solid-angle pdf the BSDF sampling gave this ray's direction; <= 0: camera ray or delta lobe */
     for (uint32_t depth = 0;; ) {
         hit_rec h;
         int hit = trace(s, o, dir, p->t_min, p->t_max, p->flags, &h, &j->st);
@@ -937,8 +958,18 @@ static void raygen_pixel_lit(job_t *j, uint32_t x, uint32_t y)
             gb_normal = ns;
             gb_dist = v3_length(v3_sub(up_o, o));
 
-            if (spec && (e->emissive[0] > 0.0f || e->emissive[1] > 0.0f || e->emissive[2] > 0.0f))
-                L = v3_add(L, v3_mul(thr, v3_make(e->emissive[0], e->emissive[1], e->emissive[2])));
+            if (e->emissive[0] > 0.0f || e->emissive[1] > 0.0f || e->emissive[2] > 0.0f) {
+                v3 le = v3_mul(thr, v3_make(e->emissive[0], e->emissive[1], e->emissive[2]));
+                if (!(prev_pdf > 0.0f)) {
+                    L = v3_add(L, le);
+                } else if (s->n_lights) {
+                    /* the light sampling of the previous vertex could have produced this point too */
+                    float cos_l = fabsf(v3_dot(ng, dir));
+                    float p_l = (s->mat_pdf_area[off->material_offset] * (h.t * h.t)) / cos_l;
+                    float w = (p->flags & 2u) ? 0.0f : lit_mis_weight(prev_pdf, p_l);
+                    L = v3_add(L, v3_scale(le, w));
+                }
+            }
 
             float u_lobe = lit_rand(uv, depth, rng_acc, seed, LIT_SEED_LOBE);
             float u1 = lit_rand(uv, depth, rng_acc, seed, LIT_SEED_U1);
@@ -969,7 +1000,7 @@ static void raygen_pixel_lit(job_t *j, uint32_t x, uint32_t y)
                     new_o = v3_sub(P, v3_scale(ng, p->normal_eps));
                     thr = v3_mul(thr, albedo);
                 }
-                spec = 1;
+                prev_pdf = 0.0f;
             } else {
                 float rough = m->roughness, metal = m->metallic;
                 float alpha = rough * rough;
@@ -998,11 +1029,12 @@ static void raygen_pixel_lit(job_t *j, uint32_t x, uint32_t y)
                     v3 wl = v3_scale(dl, inv_dist);
                     float cos_g = v3_dot(ng, wl);
                     float cos_l = fabsf(v3_dot(l->n, wl));
-                    v3 f; float pdf_unused;
-                    if (dist2 > 0.0f && cos_g > 0.0f && cos_l > 0.0f && bsdf_eval(ns, wo, wl, diff, f0, a2, p_spec, &f, &pdf_unused)) {
+                    v3 f; float p_b;
+                    if (dist2 > 0.0f && cos_g > 0.0f && cos_l > 0.0f && bsdf_eval(ns, wo, wl, diff, f0, a2, p_spec, &f, &p_b)) {
                         float cos_s = v3_dot(ns, wl);
                         float gterm = (cos_s * cos_l) / (dist2 * l->pdf_area);
-                        v3 c = v3_scale(v3_mul(v3_mul(thr, f), l->le), gterm);
+                        float p_l = (l->pdf_area * dist2) / cos_l;
+                        v3 c = v3_scale(v3_scale(v3_mul(v3_mul(thr, f), l->le), gterm), (p->flags & 2u) ? 1.0f : lit_mis_weight(p_l, p_b));
                         hit_rec sh;
                         j->st.shadow_rays++;
                         if (!trace(s, up_o, dl, p->t_min, LIT_SHADOW_TMAX, p->flags, &sh, &j->st))
@@ -1031,10 +1063,10 @@ static void raygen_pixel_lit(job_t *j, uint32_t x, uint32_t y)
                     thr = v3_mul(thr, v3_scale(f, wgt));
                     new_d = wi;
                     new_o = up_o;
+                    prev_pdf = pdf;
                 } else {
                     done = 1;
                 }
-                spec = 0;
             }
             /* Russian roulette (rchit.glsl:256-265 sketches one; this one is unbiased) */
             if (!done && depth >= 3) {

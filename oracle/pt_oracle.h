@@ -102,7 +102,9 @@ typedef struct {
     float t_max;                /* rgen.glsl:38  (10000) */
     float normal_eps;           /* rchit.glsl:242 (0.001) */
     uint32_t rng_sample_offset; /* added to accumulated_count for the RNG only (spp partition) */
-    uint32_t flags;             /* bit0: force brute-force closest hit */
+    uint32_t flags;             /* bit0: force brute-force closest hit; bit1 (checker of the checker): lit integrator without
+                                   multiple importance sampling -- light samples unweighted, emitters reached by a sampled
+                                   diffuse / glossy bounce dropped; same expectation, used by the CPU tests only */
     uint32_t integrator;        /* ORC_INTEGRATOR_* */
     uint32_t _pad;
 } orc_params;

@@ -2,10 +2,26 @@
 
 There is no CPU fallback: a missing library or a failed ptx_create raises.
 """
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
+
+# Contexts (and host Renderers) still open at interpreter exit are closed by an atexit hook, while the HIP runtime
+# is certainly alive: a __del__ that runs during module teardown can come after the runtime has begun to unload,
+# and a GPU call there ends the process with an abort.
+_live = weakref.WeakSet()
+
+
+@atexit.register
+def _close_live():
+    for obj in list(_live):
+        try:
+            obj.close()
+        except Exception:
+            pass
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libptx_amd.so")
@@ -145,6 +161,7 @@ class Context:
             raise PtxError(rc, self._L.ptx_last_error(None).decode())
         self.handle = h
         self.width = self.height = 0
+        _live.add(self)
 
     def close(self):
         if getattr(self, "handle", None):

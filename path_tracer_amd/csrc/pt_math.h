@@ -223,6 +223,15 @@ PT_HD float smith_g1(float nox, float a2)
 }
 PT_HD float pow5(float x) { float x2 = x * x; return (x2 * x2) * x; }
 
+// power heuristic (beta = 2) of the strategy with density a against the one with density b
+PT_HD float lit_mis_weight(float a, float b)
+{
+    float a2 = a * a, b2 = b * b;
+    float w = a2 / (a2 + b2);
+    if (!(w >= 0.0f)) w = 0.0f;
+    return w;
+}
+
 // f (rgb) and the mixture pdf of the opaque BSDF (Lambert + GGX) for unit wo, wi on the side of n
 PT_HD bool bsdf_eval(f3 n, f3 wo, f3 wi, f3 diff, f3 f0, float a2, float p_spec, f3 &f, float &pdf)
 {

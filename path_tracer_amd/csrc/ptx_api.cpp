@@ -619,6 +619,7 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
     // Lit integrator: the light table = every triangle whose material emits, in (instance, primitive)
     // order, picked with probability proportional to area x luminance (oracle: build_lights).
     std::vector<LightRec> lights; std::vector<float> light_cdf;
+    double light_total = 0.0;
     {
         std::vector<float> power, area;
         double total = 0.0;
@@ -651,12 +652,19 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
             lights[i].pdf_area = (float)((double)power[i] / total) / area[i];
         }
         if (!lights.empty()) light_cdf.back() = 1.0f;
+        light_total = lights.empty() ? 0.0 : total;
     }
     std::vector<LitMaterial> lit_materials(c->materials.size());
     for (size_t i = 0; i < c->materials.size(); ++i) {
         LitMaterial &lm = lit_materials[i];
         memset(&lm, 0, sizeof lm);
         memcpy(lm.emissive, c->material_ext[i].emissive, 12);
+        const float *em = c->material_ext[i].emissive;
+        if (light_total > 0.0 && (em[0] > 0.0f || em[1] > 0.0f || em[2] > 0.0f)) {
+            // the pick density seen from a BSDF-sampled ray that lands on an emitter (oracle: build_lights, mat_pdf_area)
+            float lum = (0.2126f * em[0] + 0.7152f * em[1]) + 0.0722f * em[2];
+            lm.pdf_area = (float)((double)lum / light_total);
+        }
         lm.metallic = c->materials[i].metallic;
         lm.transmission = c->material_ext[i].transmission; lm.ior = c->material_ext[i].ior;
     }

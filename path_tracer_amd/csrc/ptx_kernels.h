@@ -55,7 +55,9 @@ static_assert(sizeof(ShadeRec) == 128, "ShadeRec must be 128 bytes");
 // Lit integrator (build extension): per-material inputs beyond the ShadeRec, and the light table.
 struct alignas(16) LitMaterial {
     float emissive[3]; float metallic;
-    float transmission, ior; uint32_t _pad[2];
+    float transmission, ior;
+    float pdf_area;      // light pick density per area for a point on a triangle of this material (luminance / total power)
+    uint32_t _pad;
 };
 static_assert(sizeof(LitMaterial) == 32, "LitMaterial must be 32 bytes");
 struct alignas(16) LightRec {          // one emissive triangle, world space

@@ -644,13 +644,14 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
         const uint32_t sample = path / f.n_pixels, pix = path - sample * f.n_pixels;
         const uint32_t acc = f.mean_base + sample;
         const uint32_t rng_acc = acc + f.rng_offset;
-        const bool spec = (__float_as_uint(r2.w) & 1u) == 0u;      // bit0 set: the previous bounce was diffuse / glossy
+        const float prev_pdf = r2.w;      // solid-angle pdf the BSDF sampling gave this direction; <= 0: camera ray or delta lobe
         f3 thr = mk3(r2.x, r2.y, r2.z);
         f3 add = mk3(0.0f, 0.0f, 0.0f);
         bool have_add = false;
         f3 gb_normal = mk3(0.0f, 0.0f, 0.0f);
         float gb_dist = 3.402823466e+38f;
-        bool done = false, next_spec = true;
+        bool done = false;
+        float next_pdf = 0.0f;
         f3 new_o = o, new_d = dir;
         uint32_t id_inst = 0xFFFFFFFFu, id_prim = 0xFFFFFFFFu;
         if (tri == 0xFFFFFFFFu) {
@@ -685,9 +686,18 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
             gb_dist = length(up_o - o);
             if (depth == 0 && sample == f.ids_sample) { id_inst = __float_as_uint(s4.y); id_prim = __float_as_uint(s4.z); }
 
-            if (spec && (lm.emissive[0] > 0.0f || lm.emissive[1] > 0.0f || lm.emissive[2] > 0.0f)) {
-                add = thr * mk3(lm.emissive[0], lm.emissive[1], lm.emissive[2]);
-                have_add = true;
+            if (lm.emissive[0] > 0.0f || lm.emissive[1] > 0.0f || lm.emissive[2] > 0.0f) {
+                const f3 le = thr * mk3(lm.emissive[0], lm.emissive[1], lm.emissive[2]);
+                if (!(prev_pdf > 0.0f)) {
+                    add = le;
+                    have_add = true;
+                } else if (sc.n_lights) {
+                    // the light sampling of the previous vertex could have produced this point too
+                    const float cos_l = fabsf(dot(ng, dir));
+                    const float p_l = (lm.pdf_area * (hr.x * hr.x)) / cos_l;
+                    add = le * lit_mis_weight(prev_pdf, p_l);
+                    have_add = true;
+                }
             }
             const float u_lobe = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedLobe);
             const float u1 = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedU1);
@@ -718,7 +728,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
                     new_o = P - ng * f.normal_eps;
                     thr = thr * albedo;
                 }
-                next_spec = true;
+                next_pdf = 0.0f;
             } else {
                 const float rough = t1.w, metal = lm.metallic;
                 float alpha = rough * rough;
@@ -748,11 +758,12 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
                     const f3 wl = dl * inv_dist;
                     const float cos_g = dot(ng, wl);
                     const float cos_l = fabsf(dot(mk3(l3.x, l3.y, l3.z), wl));
-                    f3 fb; float pdf_unused;
-                    if (dist2 > 0.0f && cos_g > 0.0f && cos_l > 0.0f && bsdf_eval(ns, wo, wl, diff, f0, a2, p_spec, fb, pdf_unused)) {
+                    f3 fb; float p_b;
+                    if (dist2 > 0.0f && cos_g > 0.0f && cos_l > 0.0f && bsdf_eval(ns, wo, wl, diff, f0, a2, p_spec, fb, p_b)) {
                         const float cos_s = dot(ns, wl);
                         const float gterm = (cos_s * cos_l) / (dist2 * l0.w);
-                        const f3 c = ((thr * fb) * mk3(l1.w, l2.w, l3.w)) * gterm;
+                        const float p_l = (l0.w * dist2) / cos_l;
+                        const f3 c = (((thr * fb) * mk3(l1.w, l2.w, l3.w)) * gterm) * lit_mis_weight(p_l, p_b);
                         want_shadow = true;
                         q0 = make_float4(up_o.x, up_o.y, up_o.z, r0.w);
                         q1 = make_float4(dl.x, dl.y, dl.z, 0.0f);
@@ -785,10 +796,10 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
                     thr = thr * (fb * wgt);
                     new_d = wi;
                     new_o = up_o;
+                    next_pdf = pdf;
                 } else {
                     done = true;
                 }
-                next_spec = false;
             }
             // Russian roulette
             if (!done && depth >= 3u) {
@@ -822,7 +833,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
             alive = true;
             o0 = make_float4(new_o.x, new_o.y, new_o.z, r0.w);
             o1 = make_float4(new_d.x, new_d.y, new_d.z, r1.w);
-            o2 = make_float4(thr.x, thr.y, thr.z, __uint_as_float(next_spec ? 0u : 1u));
+            o2 = make_float4(thr.x, thr.y, thr.z, next_pdf);
             float ix, iy, iz;
             uint32_t oct = ray_slab_setup(new_o, new_d, ix, iy, iz);
             o3 = make_float4(ix, iy, iz, __uint_as_float(oct));

@@ -104,6 +104,7 @@ class Renderer:
                                            C.byref(h)))
         self.handle = h
         self.width, self.height = width, height
+        capi._live.add(self)
         # a non-owning capi.Context view of the renderer's ptx context (stats, readback, multi-GPU export)
         self.ctx = capi.Context.__new__(capi.Context)
         self.ctx._L = capi.load()

@@ -233,3 +233,26 @@ def test_texture_bilinear_filter(oracle):
     lut = np.array([oracle.lib().orc_srgb_to_linear(c) for c in (0, 85, 170, 255)])
     xc = np.clip(x, 0, 3); j = np.minimum(np.floor(xc).astype(int), 2); f = xc - j
     np.testing.assert_allclose(srgb[sel, 0], (lut[j] * (1 - f) + lut[j + 1] * f)[sel], atol=1e-5)
+
+
+def test_mis_keeps_the_expectation(oracle):
+    """Multiple importance sampling re-weights the two ways of reaching an emitter; the image it converges to is
+    the one plain next-event estimation converges to (oracle flag bit1), and its noise is lower."""
+    ing = cornell_lit()
+    sc = oracle.scene_from_ingest(ing, options=oracle.SCENE_WORLD_NORMALS, with_material_ext=True)
+    cam = oracle.camera_matrices([0, 1.0, 3.9], oracle.yaw_quat(0), np.deg2rad(np.float32(40)), 1.0, 0.1, 1000.0)
+    W, spp = 24, 3072
+    imgs = {}
+    for name, flags in (("mis", 0), ("nee", 2)):
+        halves = [sc.render(cam, W, W, spp, seed, params=oracle.default_params(max_depth=8, integrator=oracle.INTEGRATOR_LIT, flags=flags),
+                            want_ids=False)["albedo"][..., :3].astype(np.float64) for seed in (SEED, SEED + 99)]
+        imgs[name] = halves
+    mis = (imgs["mis"][0] + imgs["mis"][1]) / 2
+    nee = (imgs["nee"][0] + imgs["nee"][1]) / 2
+    # image-wide energy: equal within the noise of the estimators
+    assert abs(mis.mean() - nee.mean()) < 0.02 * nee.mean(), (mis.mean(), nee.mean())
+    # per pixel: the difference between the two estimators is no larger than what two independent runs of one of them show
+    noise_nee = np.abs(imgs["nee"][0] - imgs["nee"][1]).mean()
+    noise_mis = np.abs(imgs["mis"][0] - imgs["mis"][1]).mean()
+    assert np.abs(mis - nee).mean() < 1.5 * max(noise_nee, noise_mis), (np.abs(mis - nee).mean(), noise_nee, noise_mis)
+    assert noise_mis < noise_nee, (noise_mis, noise_nee)
