@@ -105,7 +105,10 @@ typedef struct {
     float emissive[3];            /* emissiveFactor x KHR_materials_emissive_strength, linear radiance; 0 */
     float transmission;           /* KHR_materials_transmission, 0..1; 0 */
     float ior;                    /* KHR_materials_ior; 1.5 */
-    uint32_t _pad[3];
+    uint32_t mr_texture;          /* glTF metallicRoughnessTexture as bindless index + 1 (0: none), added with
+                                     ptx_add_texture WITHOUT the sRGB bit: roughness = roughnessFactor x G,
+                                     metallic = metallicFactor x B at the hit's uv (lit integrator only) */
+    uint32_t _pad[2];
 } ptx_material_ext;
 
 typedef enum {

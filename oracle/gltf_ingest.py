@@ -25,7 +25,7 @@ OFFSETS_DTYPE = np.dtype([("vertex_offset", "<u4"), ("vertex_count", "<u4"), ("m
                           ("padding", "<u4"), ("index_offset", "<u4"), ("index_count", "<u4")])
 INSTANCE_DTYPE = np.dtype([("xform", "<f4", (3, 4)), ("geometry", "<u4"), ("off", OFFSETS_DTYPE)])
 # build extension: what glTF materials carry beyond material.rs:70-76
-MATERIAL_EXT_DTYPE = np.dtype([("emissive", "<f4", 3), ("transmission", "<f4"), ("ior", "<f4"), ("_pad", "<u4", 3)])
+MATERIAL_EXT_DTYPE = np.dtype([("emissive", "<f4", 3), ("transmission", "<f4"), ("ior", "<f4"), ("mr_texture", "<u4"), ("_pad", "<u4", 2)])
 assert MATERIAL_EXT_DTYPE.itemsize == 32
 assert VERTEX_DTYPE.itemsize == 48 and MATERIAL_DTYPE.itemsize == 32
 assert OFFSETS_DTYPE.itemsize == 24 and INSTANCE_DTYPE.itemsize == 76
@@ -226,6 +226,32 @@ class IngestedScene:
         self.geometries[ident] = geom
         return geom
 
+    def _texture_from_gltf(self, doc, tex, base, decode_image, srgb):
+        """Texture::from_gltf + Renderer::add_texture (graphics.rs:383-516, renderer.rs:867-904): bindless index,
+        cached by ident."""
+        gtex = doc["textures"][tex["index"]]
+        image = doc["images"][gtex["source"]]
+        ident = "gltf_%s" % image["uri"]                                     # material.rs:59-61
+        flags = 1 if srgb else 0                                             # R8G8B8A8_SRGB / _UNORM
+        if not srgb:
+            ident += "#unorm"
+        if not self.ref_quirks:
+            samp = doc.get("samplers", [{}])[gtex["sampler"]] if "sampler" in gtex else {}
+            if samp.get("wrapS", 10497) == 10497 and samp.get("wrapT", 10497) == 10497:
+                flags |= 2                                                   # wrap = repeat (glTF default)
+                ident += "#repeat"
+            if samp.get("magFilter", 9729) == 9729:
+                flags |= 4                                                   # LINEAR (also when the sampler leaves it open)
+                ident += "#linear"
+        if ident not in self.texture_lookup:                                 # graphics.rs:396-398
+            rgba = np.asarray((decode_image or decode_image_pil)(os.path.join(base, image["uri"])), np.uint8)
+            if rgba.shape[2] == 3:                                            # graphics.rs:507-516
+                rgba = np.concatenate([rgba, np.full(rgba.shape[:2] + (1,), 255, np.uint8)], axis=2)
+            rgba = np.ascontiguousarray(rgba)
+            self.textures.append((rgba, flags))
+            self.texture_lookup[ident] = len(self.textures) - 1
+        return self.texture_lookup[ident]
+
     def _material_from_gltf(self, doc, mat_idx, base, decode_image):
         """material.rs:34-90.  Every primitive appends a new Material row (no dedup)."""
         m = np.zeros(1, dtype=MATERIAL_DTYPE)
@@ -245,27 +271,14 @@ class IngestedScene:
         m["roughness"] = np.float32(pbr.get("roughnessFactor", 1.0))
         tex = pbr.get("baseColorTexture")
         if tex is not None:
-            gtex = doc["textures"][tex["index"]]
-            image = doc["images"][gtex["source"]]
-            ident = "gltf_%s" % image["uri"]                                     # material.rs:59-61
-            flags = 1                                                            # R8G8B8A8_SRGB
-            if not self.ref_quirks:
-                samp = doc.get("samplers", [{}])[gtex["sampler"]] if "sampler" in gtex else {}
-                if samp.get("wrapS", 10497) == 10497 and samp.get("wrapT", 10497) == 10497:
-                    flags |= 2                                                   # wrap = repeat (glTF default)
-                    ident += "#repeat"
-                if samp.get("magFilter", 9729) == 9729:
-                    flags |= 4                                                   # LINEAR (also when the sampler leaves it open)
-                    ident += "#linear"
-            if ident not in self.texture_lookup:                                 # graphics.rs:396-398
-                rgba = np.asarray((decode_image or decode_image_pil)(os.path.join(base, image["uri"])), np.uint8)
-                if rgba.shape[2] == 3:                                            # graphics.rs:507-516
-                    rgba = np.concatenate([rgba, np.full(rgba.shape[:2] + (1,), 255, np.uint8)], axis=2)
-                rgba = np.ascontiguousarray(rgba)
-                self.textures.append((rgba, flags))
-                self.texture_lookup[ident] = len(self.textures) - 1
+            index = self._texture_from_gltf(doc, tex, base, decode_image, srgb=True)
             m["has_base_texture"] = 1
-            m["base_texture_indice"] = self.texture_lookup[ident]
+            m["base_texture_indice"] = index
+        mrt = pbr.get("metallicRoughnessTexture")
+        if mrt is not None and not self.ref_quirks:          # build extension (lit integrator); the reference never reads it
+            uri = doc["images"][doc["textures"][mrt["index"]]["source"]]["uri"]
+            if os.path.exists(os.path.join(base, uri)):     # optional: without the file the factors stand alone
+                ext["mr_texture"] = self._texture_from_gltf(doc, mrt, base, decode_image, srgb=False) + 1
         return self.add_material(m, ext)
 
     def instances(self, xform_fn):

@@ -426,7 +426,7 @@ static inline v3 normal_to_world(const float c[9], v3 n)
                    (c[6] * n.x + c[7] * n.y) + c[8] * n.z);
 }
 
-static const orc_material_ext g_no_ext = { { 0.0f, 0.0f, 0.0f }, 0.0f, 1.5f, { 0, 0, 0 } };
+static const orc_material_ext g_no_ext = { { 0.0f, 0.0f, 0.0f }, 0.0f, 1.5f, 0, { 0, 0 } };
 static inline const orc_material_ext *material_ext(const orc_scene *s, uint32_t m)
 {
     return s->d.material_ext ? &s->d.material_ext[m] : &g_no_ext;
@@ -1003,6 +1003,11 @@ static void raygen_pixel_lit(job_t *j, uint32_t x, uint32_t y)
                 prev_pdf = 0.0f;
             } else {
                 float rough = m->roughness, metal = m->metallic;
+                if (e->mr_texture) {        /* glTF: G = roughness, B = metallic, linear texels, multiplied into the factors */
+                    v3 mr = sample_texture(&d->textures[e->mr_texture - 1], tu, tv);
+                    rough = rough * mr.y;
+                    metal = metal * mr.z;
+                }
                 float alpha = rough * rough;
                 if (alpha < 0.0025f) alpha = 0.0025f;
                 float a2 = alpha * alpha;

@@ -84,7 +84,9 @@ typedef struct {
     float emissive[3];      /* glTF emissiveFactor x KHR_materials_emissive_strength (linear radiance) */
     float transmission;     /* KHR_materials_transmission: probability of the smooth dielectric lobe */
     float ior;              /* KHR_materials_ior (1.5) */
-    uint32_t _pad[3];
+    uint32_t mr_texture;    /* glTF metallicRoughnessTexture: texture index + 1, 0 = none; G scales the roughness factor,
+                               B the metallic factor (lit integrator) */
+    uint32_t _pad[2];
 } orc_material_ext;
 
 /* scene options (orc_scene_desc.options); 0 = the reference's behaviour, quirks included */

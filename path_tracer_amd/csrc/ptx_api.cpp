@@ -390,8 +390,12 @@ int ptx_set_material_ext(ptx_context *c, uint32_t index, const ptx_material_ext 
     if (!(ext->ior > 0.0f) || !(ext->transmission >= 0.0f && ext->transmission <= 1.0f) ||
         !(ext->emissive[0] >= 0.0f && ext->emissive[1] >= 0.0f && ext->emissive[2] >= 0.0f))
         return fail(c, PTX_ERR_INVALID, "ptx_set_material_ext: ior must be > 0, transmission in [0,1], emission >= 0");
+    if (ext->mr_texture > c->textures.size())
+        return fail(c, PTX_ERR_INVALID, "ptx_set_material_ext: mr_texture names a texture that has not been added");
+    if (ext->mr_texture && (c->textures[ext->mr_texture - 1].srgb & PTX_TEXTURE_SRGB))
+        return fail(c, PTX_ERR_INVALID, "ptx_set_material_ext: mr_texture must be a linear (non-sRGB) texture");
     c->material_ext[index] = *ext;
-    c->material_ext[index]._pad[0] = c->material_ext[index]._pad[1] = c->material_ext[index]._pad[2] = 0;
+    c->material_ext[index]._pad[0] = c->material_ext[index]._pad[1] = 0;
     return PTX_OK;
 }
 
@@ -667,6 +671,7 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
         }
         lm.metallic = c->materials[i].metallic;
         lm.transmission = c->material_ext[i].transmission; lm.ior = c->material_ext[i].ior;
+        lm.mr_texture = c->material_ext[i].mr_texture;
     }
 
     lap("lights");

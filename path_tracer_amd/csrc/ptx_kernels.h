@@ -57,7 +57,7 @@ struct alignas(16) LitMaterial {
     float emissive[3]; float metallic;
     float transmission, ior;
     float pdf_area;      // light pick density per area for a point on a triangle of this material (luminance / total power)
-    uint32_t _pad;
+    uint32_t mr_texture; // metallic-roughness texture index + 1, 0 = none
 };
 static_assert(sizeof(LitMaterial) == 32, "LitMaterial must be 32 bytes");
 struct alignas(16) LightRec {          // one emissive triangle, world space

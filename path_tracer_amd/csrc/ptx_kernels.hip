@@ -730,7 +730,13 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
                 }
                 next_pdf = 0.0f;
             } else {
-                const float rough = t1.w, metal = lm.metallic;
+                float rough = t1.w, metal = lm.metallic;
+                if (lm.mr_texture) {        // glTF: G = roughness, B = metallic, linear texels, multiplied into the factors
+                    const uint32_t mt = lm.mr_texture - 1u;
+                    const f3 mr = mt < kLdsTextures ? sample_texture(s_tex[mt], s_lut, tu, tv) : sample_texture(sc.textures[mt], s_lut, tu, tv);
+                    rough = rough * mr.y;
+                    metal = metal * mr.z;
+                }
                 float alpha = rough * rough;
                 if (alpha < 0.0025f) alpha = 0.0025f;
                 const float a2 = alpha * alpha;

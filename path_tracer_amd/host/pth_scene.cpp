@@ -94,6 +94,53 @@ uint32_t read_index(const AccessorView &v, size_t i)
     }
 }
 
+// Texture::from_gltf + Renderer::add_texture (graphics.rs:383-516, renderer.rs:867-904), cached by ident
+Texture texture_from_gltf(const Json &doc, const Json &info, Renderer &renderer, const std::string &gltf_dir, bool srgb)
+{
+    const Json &tex = doc.at("textures").at((size_t)info.get_int("index", 0));
+    const Json &image = doc.at("images").at((size_t)tex.get_int("source", 0));
+    if (!image.has("uri")) throw std::runtime_error("glTF: buffer-view images are not supported");
+    std::string uri = image.get_string("uri", "");
+    std::string ident = "gltf_" + uri;                       // material.rs:59-61
+    if (!srgb) ident += "#unorm";
+    // graphics.rs:446-451 reads the glTF sampler's wrap / filter modes and then builds a default
+    // sampler (nearest, clamp-to-edge, todo.md:6).  Without the reference's quirks the wrap mode is honoured
+    // (glTF default: repeat, 10497), and so is the magnification filter (LINEAR = 9729, also when the
+    // sampler leaves it open).
+    bool repeat = false, linear = false;
+    if (!renderer.ref_quirks()) {
+        int64_t ws = 10497, wt = 10497, mag = 9729;
+        if (tex.has("sampler")) {
+            const Json &smp = doc.at("samplers").at((size_t)tex.get_int("sampler", 0));
+            ws = smp.get_int("wrapS", 10497); wt = smp.get_int("wrapT", 10497);
+            mag = smp.get_int("magFilter", 9729);
+        }
+        repeat = ws == 10497 && wt == 10497;
+        if (repeat) ident += "#repeat";
+        linear = mag == 9729;
+        if (linear) ident += "#linear";
+    }
+    // gltf::image::Data::from_source decodes on every call (material.rs:64-65); the
+    // renderer's ident cache then skips the upload (graphics.rs:396-398).  Decoding is
+    // skipped here when the ident is cached -- same result, less work.
+    if (const Texture *cached = renderer.lookup_texture(ident)) return *cached;
+    Texture t;
+    Image img; std::string err;
+    if (!decode_image_file(gltf_dir + "/" + uri, img, err)) throw std::runtime_error(err);
+    std::vector<uint8_t> rgba;
+    const uint8_t *px = img.pixels.data();
+    if (img.channels == 3) {                              // graphics.rs:507-516
+        rgba.resize((size_t)img.width * img.height * 4);
+        for (size_t i = 0; i < (size_t)img.width * img.height; ++i) {
+            rgba[i * 4] = px[i * 3]; rgba[i * 4 + 1] = px[i * 3 + 1]; rgba[i * 4 + 2] = px[i * 3 + 2]; rgba[i * 4 + 3] = 255;
+        }
+        px = rgba.data();
+    }
+    t.bindless_indice = renderer.add_texture(px, img.width, img.height, srgb, repeat, linear);   // R8G8B8A8_SRGB / _UNORM
+    renderer.add_texture_to_lookup_map(ident, t);
+    return t;
+}
+
 // material.rs:34-90
 Material material_from_gltf(const Json &doc, const Json *gltf_mat, Renderer &renderer, const std::string &gltf_dir)
 {
@@ -106,52 +153,21 @@ Material material_from_gltf(const Json &doc, const Json *gltf_mat, Renderer &ren
         m.metallic = (float)pbr->get_number("metallicFactor", 1.0);
         m.roughness = (float)pbr->get_number("roughnessFactor", 1.0);
         if (const Json *bt = pbr->find("baseColorTexture")) {
-            const Json &tex = doc.at("textures").at((size_t)bt->get_int("index", 0));
-            const Json &image = doc.at("images").at((size_t)tex.get_int("source", 0));
-            if (!image.has("uri")) throw std::runtime_error("glTF: buffer-view images are not supported");
-            std::string uri = image.get_string("uri", "");
-            std::string ident = "gltf_" + uri;                       // material.rs:59-61
-            // graphics.rs:446-451 reads the glTF sampler's wrap / filter modes and then builds a default
-            // sampler (clamp-to-edge, todo.md:6).  Without the reference's quirks the wrap mode is honoured
-            // (glTF default: repeat, 10497).
-            // and so is the magnification filter (LINEAR = 9729, also when the sampler leaves it open).
-            bool repeat = false, linear = false;
-            if (!renderer.ref_quirks()) {
-                int64_t ws = 10497, wt = 10497, mag = 9729;
-                if (tex.has("sampler")) {
-                    const Json &smp = doc.at("samplers").at((size_t)tex.get_int("sampler", 0));
-                    ws = smp.get_int("wrapS", 10497); wt = smp.get_int("wrapT", 10497);
-                    mag = smp.get_int("magFilter", 9729);
-                }
-                repeat = ws == 10497 && wt == 10497;
-                if (repeat) ident += "#repeat";
-                linear = mag == 9729;
-                if (linear) ident += "#linear";
-            }
-            // gltf::image::Data::from_source decodes on every call (material.rs:64-65); the
-            // renderer's ident cache then skips the upload (graphics.rs:396-398).  Decoding is
-            // skipped here when the ident is cached -- same result, less work.
-            const Texture *cached = renderer.lookup_texture(ident);
-            Texture t;
-            if (cached) t = *cached;
-            else {
-                Image img; std::string err;
-                if (!decode_image_file(gltf_dir + "/" + uri, img, err)) throw std::runtime_error(err);
-                std::vector<uint8_t> rgba;
-                const uint8_t *px = img.pixels.data();
-                if (img.channels == 3) {                              // graphics.rs:507-516
-                    rgba.resize((size_t)img.width * img.height * 4);
-                    for (size_t i = 0; i < (size_t)img.width * img.height; ++i) {
-                        rgba[i * 4] = px[i * 3]; rgba[i * 4 + 1] = px[i * 3 + 1]; rgba[i * 4 + 2] = px[i * 3 + 2]; rgba[i * 4 + 3] = 255;
-                    }
-                    px = rgba.data();
-                }
-                t.bindless_indice = renderer.add_texture(px, img.width, img.height, true, repeat, linear);   // R8G8B8A8_SRGB
-                renderer.add_texture_to_lookup_map(ident, t);
-            }
+            Texture t = texture_from_gltf(doc, *bt, renderer, gltf_dir, true);
             m.has_base_texture = true;
             m.base_texture_indice = t.bindless_indice;
         }
+        // build extension (lit integrator): G = roughness, B = metallic; the reference never reads this texture
+        if (const Json *mt = pbr->find("metallicRoughnessTexture"))
+            if (!renderer.ref_quirks()) {
+                // optional: without the image file the factors stand alone
+                const Json &image = doc.at("images").at((size_t)doc.at("textures").at((size_t)mt->get_int("index", 0)).get_int("source", 0));
+                std::string path = gltf_dir + "/" + image.get_string("uri", "");
+                if (FILE *probe = fopen(path.c_str(), "rb")) {
+                    fclose(probe);
+                    m.mr_texture = texture_from_gltf(doc, *mt, renderer, gltf_dir, false).bindless_indice + 1u;
+                }
+            }
     }
     if (gltf_mat) {
         // build extension: emission / transmission / ior (ignored by the reference and by its integrator)
@@ -172,6 +188,7 @@ Material material_from_gltf(const Json &doc, const Json *gltf_mat, Renderer &ren
     m.shared_buffer_index = renderer.scene.add_material(sm);
     ptx_material_ext ext; memset(&ext, 0, sizeof ext);
     memcpy(ext.emissive, m.emissive, 12); ext.transmission = m.transmission; ext.ior = m.ior;
+    ext.mr_texture = m.mr_texture;
     renderer.scene.set_material_ext(m.shared_buffer_index, ext);
     return m;
 }

@@ -51,6 +51,7 @@ struct Material {
     float emissive[3] = {0, 0, 0};      // emissiveFactor x KHR_materials_emissive_strength
     float transmission = 0.0f;          // KHR_materials_transmission
     float ior = 1.5f;                   // KHR_materials_ior
+    uint32_t mr_texture = 0;            // metallicRoughnessTexture: bindless index + 1, 0 = none (not under ref quirks)
     uint64_t get_shared_buffer_offset() const { return shared_buffer_index; }
 };
 

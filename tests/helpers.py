@@ -143,3 +143,57 @@ def rel_mse(a, b, eps=1e-2):
     a = np.asarray(a, np.float64)[..., :3]
     b = np.asarray(b, np.float64)[..., :3]
     return float(np.mean((a - b) ** 2 / (b * b + eps)))
+
+
+def write_mr_quad_gltf(dirpath):
+    """A lit test scene written from scratch: a 4 x 4 m floor quad with uv in [0, 2] carrying a base-colour texture
+    and a metallicRoughnessTexture (procedural PNGs, G = roughness, B = metallic), under a small emissive quad.
+    Returns the .gltf path."""
+    import json
+    import struct
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:32, 0:32]
+    mr = np.zeros((32, 32, 3), np.uint8)
+    mr[..., 1] = np.where((xx // 4 + yy // 4) % 2 == 0, 40, 230)          # roughness checker
+    mr[..., 2] = np.where(xx < 16, 255, 0)                                 # metallic half
+    mr[..., 0] = rng.integers(0, 256, (32, 32))                            # occlusion channel: unused
+    Image.fromarray(mr).save(os.path.join(dirpath, "mr.png"))
+    Image.fromarray(rng.integers(60, 256, (16, 16, 3), dtype=np.uint8)).save(os.path.join(dirpath, "base.png"))
+
+    def quad(y, half, flip):
+        p = [[-half, y, -half], [half, y, -half], [half, y, half], [-half, y, half]]
+        uv = [[0, 0], [2, 0], [2, 2], [0, 2]]
+        idx = [0, 2, 1, 0, 3, 2] if not flip else [0, 1, 2, 0, 2, 3]
+        return p, uv, idx
+    blob = b""
+    views, accessors, meshes = [], [], []
+    for name, (p, uv, idx), mat in (("floor", quad(0.0, 2.0, False), 0), ("lamp", quad(2.0, 0.3, True), 1)):
+        nrm = [[0, 1, 0]] * 4 if name == "floor" else [[0, -1, 0]] * 4
+        first = len(accessors)
+        for data, comp, typ in ((p, "f", "VEC3"), (nrm, "f", "VEC3"), (uv, "f", "VEC2"), (idx, "H", "SCALAR")):
+            flat = [x for row in data for x in row] if typ != "SCALAR" else data
+            raw = struct.pack("<%d%s" % (len(flat), comp), *flat)
+            raw += b"\0" * (-len(raw) % 4)
+            views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": len(raw)})
+            acc = {"bufferView": len(views) - 1, "componentType": 5126 if comp == "f" else 5123, "count": len(data), "type": typ}
+            if typ == "VEC3" and data is p:
+                acc["min"] = [min(r[i] for r in p) for i in range(3)]; acc["max"] = [max(r[i] for r in p) for i in range(3)]
+            accessors.append(acc)
+            blob += raw
+        meshes.append({"name": name, "primitives": [{"attributes": {"POSITION": first, "NORMAL": first + 1, "TEXCOORD_0": first + 2},
+                                                       "indices": first + 3, "material": mat}]})
+    open(os.path.join(dirpath, "mrquad.bin"), "wb").write(blob)
+    doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0, 1]}],
+           "nodes": [{"name": "floor", "mesh": 0}, {"name": "lamp", "mesh": 1}], "meshes": meshes,
+           "materials": [{"name": "floor", "pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "metallicRoughnessTexture": {"index": 1},
+                                                                      "roughnessFactor": 0.9, "metallicFactor": 0.8}},
+                         {"name": "lamp", "emissiveFactor": [1.0, 0.9, 0.7], "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 12.0}},
+                          "pbrMetallicRoughness": {"baseColorFactor": [0, 0, 0, 1]}}],
+           "textures": [{"source": 0, "sampler": 0}, {"source": 1, "sampler": 1}],
+           "samplers": [{"magFilter": 9729, "wrapS": 10497, "wrapT": 10497}, {"magFilter": 9728, "wrapS": 33071, "wrapT": 33071}],
+           "images": [{"uri": "base.png"}, {"uri": "mr.png"}],
+           "buffers": [{"uri": "mrquad.bin", "byteLength": len(blob)}], "bufferViews": views, "accessors": accessors}
+    path = os.path.join(dirpath, "mrquad.gltf")
+    json.dump(doc, open(path, "w"))
+    return path

@@ -97,6 +97,11 @@ def test_textured_lit_and_texture_options(oracle, gpu_ctx_factory):
     opts = capi.SCENE_WORLD_NORMALS | capi.SCENE_TEXTURE_TIMES_FACTOR
     ing = lion_boulder()
     ing.textures = [(rgba, flags | capi.TEXTURE_LINEAR) for rgba, flags in ing.textures]      # 2k textures, bilinear
+    rng = np.random.default_rng(3)                 # synthetic metallic-roughness maps on the real uv layouts
+    for i in range(len(ing.materials)):
+        ing.textures.append((rng.integers(0, 256, (64, 64, 4), dtype=np.uint8), capi.TEXTURE_REPEAT | (capi.TEXTURE_LINEAR if i else 0)))
+        ing.material_ext[i]["mr_texture"] = len(ing.textures)
+        ing.materials[i]["metallic"] = 1.0
     ctx = gpu_ctx_factory()
     upload(ctx, ing, oracle, options=opts, with_material_ext=True)
     sc = oracle.scene_from_ingest(ing, options=opts, with_material_ext=True)
@@ -225,3 +230,42 @@ def test_lit_scene_motion_device_refit_and_moving_emitter(oracle, monkeypatch):
     st = move(4, [0.2, -0.05, 0.1])         # the light quad: host refit, new light table
     assert st["bvh_refits"] == 2 and st["bvh_device_refits"] == 1 and st["bvh_builds"] == 1
     r.close()
+
+
+def test_host_metallic_roughness_texture(oracle, tmp_path):
+    """metallicRoughnessTexture through the C++ host's glTF import (linear texture, its own sampler) against the
+    oracle-side ingest of the same file, lit integrator."""
+    from helpers import write_mr_quad_gltf
+    from oracle.gltf_ingest import IngestedScene
+    from path_tracer_amd import capi, host
+    path = write_mr_quad_gltf(str(tmp_path))
+    r = host.Renderer(96, 96, 0)
+    r.set_ref_quirks(False)
+    r.import_gltf(path)
+    fov = np.deg2rad(np.float32(55.0))
+    r.set_camera([0.0, 1.2, 3.5], host.yaw_quat(0.0), fov, 0.1, 1000.0)
+    r.set_seed(SEED, fixed=True)
+    r.set_params(capi.default_params(max_depth=6, integrator=capi.INTEGRATOR_LIT))
+    r.record_commands(); r.record_commands()
+    r.record_commands_batch(4)
+    got = {k: r.read_image(v) for k, v in (("albedo", capi.IMAGE_ALBEDO), ("normal", capi.IMAGE_NORMAL),
+                                           ("depth", capi.IMAGE_DEPTH), ("ids", capi.IMAGE_PRIMARY_ID))}
+    ing = IngestedScene(ref_quirks=False)
+    ing.import_gltf(path)
+    assert ing.material_ext["mr_texture"].tolist() == [2, 0]
+    sc = oracle.scene_from_ingest(ing, options=oracle.SCENE_WORLD_NORMALS | oracle.SCENE_TEXTURE_TIMES_FACTOR, with_material_ext=True)
+    cam = oracle.camera_matrices([0.0, 1.2, 3.5], oracle.yaw_quat(0), fov, 1.0, 0.1, 1000.0)
+    want = sc.render(cam, 96, 96, 4, SEED, params=oracle.default_params(max_depth=6, integrator=oracle.INTEGRATOR_LIT))
+    assert_images_bit_equal(got, want, "host mr texture")
+    assert want["stats"]["shadow_rays"] > 0 and want["stats"]["textured_hits"] > 0
+    r.close()
+    ctx = capi.Context(0)
+    m = np.zeros(1, dtype=capi.MATERIAL_DTYPE)
+    ctx.add_material(m)
+    e = np.zeros(1, dtype=capi.MATERIAL_EXT_DTYPE); e["ior"] = 1.5; e["mr_texture"] = 1
+    with pytest.raises(capi.PtxError):
+        ctx.set_material_ext(0, e)                       # no such texture yet
+    ctx.add_texture(np.zeros((2, 2, 4), np.uint8), capi.TEXTURE_SRGB)
+    with pytest.raises(capi.PtxError):
+        ctx.set_material_ext(0, e)                       # sRGB texture refused
+    ctx.close()

@@ -256,3 +256,29 @@ def test_mis_keeps_the_expectation(oracle):
     noise_mis = np.abs(imgs["mis"][0] - imgs["mis"][1]).mean()
     assert np.abs(mis - nee).mean() < 1.5 * max(noise_nee, noise_mis), (np.abs(mis - nee).mean(), noise_nee, noise_mis)
     assert noise_mis < noise_nee, (noise_mis, noise_nee)
+
+
+def test_metallic_roughness_texture_ingest_and_effect(oracle, tmp_path):
+    """glTF metallicRoughnessTexture: read only without the reference's quirks, as a linear (non-sRGB) texture with its
+    own sampler; optional when the image file is absent; it changes what the lit integrator renders."""
+    from helpers import write_mr_quad_gltf
+    from oracle.gltf_ingest import IngestedScene
+    path = write_mr_quad_gltf(str(tmp_path))
+    ref = IngestedScene()
+    ref.import_gltf(path)
+    assert ref.material_ext["mr_texture"].tolist() == [0, 0] and len(ref.textures) == 1
+    ing = IngestedScene(ref_quirks=False)
+    ing.import_gltf(path)
+    assert ing.material_ext["mr_texture"].tolist() == [2, 0]
+    assert [f for _, f in ing.textures] == [1 | 2 | 4, 0]              # base: sRGB, repeat, linear; mr: UNORM, clamp, nearest
+    cam = oracle.camera_matrices([0, 1.2, 3.5], oracle.yaw_quat(0), np.deg2rad(np.float32(55)), 1.0, 0.1, 1000.0)
+    P = oracle.default_params(max_depth=4, integrator=oracle.INTEGRATOR_LIT)
+    opts = oracle.SCENE_WORLD_NORMALS | oracle.SCENE_TEXTURE_TIMES_FACTOR
+    with_tex = oracle.scene_from_ingest(ing, options=opts, with_material_ext=True).render(cam, 48, 48, 16, SEED, params=P)["albedo"]
+    ing.material_ext["mr_texture"][0] = 0
+    without = oracle.scene_from_ingest(ing, options=opts, with_material_ext=True).render(cam, 48, 48, 16, SEED, params=P)["albedo"]
+    assert np.isfinite(with_tex).all() and np.abs(with_tex - without).mean() > 1e-3
+    os.remove(os.path.join(str(tmp_path), "mr.png"))
+    gone = IngestedScene(ref_quirks=False)
+    gone.import_gltf(path)
+    assert gone.material_ext["mr_texture"].tolist() == [0, 0] and len(gone.textures) == 1
