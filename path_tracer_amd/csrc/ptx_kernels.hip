@@ -611,21 +611,23 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
     __shared__ uint32_t s_cnt[kShadeBlock / 64];
     __shared__ uint32_t s_base, s_hits;
 
-    const uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x;
-    if (blockIdx.x * kShadeBlock >= counters[depth]) return;
-    if (threadIdx.x == 0) s_hits = 0;
-    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
-    float2 hr = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
-    if (i < capacity) {
-        r0 = rays_in.org[i]; r1 = rays_in.dir[i]; r2 = rays_in.thr[i];
-        hr = *reinterpret_cast<const float2 *>(hits + i);
-    }
+    // capped grid, tiles of kShadeBlock rays (see k_shade)
     const uint32_t n_live = counters[depth];
+    if ((uint64_t)blockIdx.x * kShadeBlock >= n_live) return;
+    if (threadIdx.x == 0) s_hits = 0;
     if (threadIdx.x < 256) s_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];
     {
         const uint32_t nw = (sc.n_textures < kLdsTextures ? sc.n_textures : kLdsTextures) * (uint32_t)(sizeof(TexDesc) / 4);
         for (uint32_t w = threadIdx.x; w < nw; w += kShadeBlock)
             reinterpret_cast<uint32_t *>(s_tex)[w] = reinterpret_cast<const uint32_t *>(sc.textures)[w];
+    }
+    for (uint32_t tile = blockIdx.x; (uint64_t)tile * kShadeBlock < n_live; tile += gridDim.x) {
+    const uint32_t i = tile * kShadeBlock + threadIdx.x;
+    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
+    float2 hr = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
+    if (i < capacity) {
+        r0 = rays_in.org[i]; r1 = rays_in.dir[i]; r2 = rays_in.thr[i];
+        hr = *reinterpret_cast<const float2 *>(hits + i);
     }
     const bool valid = i < capacity && i < n_live;
     const uint32_t tri = valid ? __float_as_uint(hr.y) : 0xFFFFFFFFu;
@@ -853,23 +855,25 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
         if ((threadIdx.x & 63u) == 0 && hitm) atomicAdd(&s_hits, (uint32_t)__popcll(hitm));
     }
     const uint32_t slot = block_reserve(alive, bs, &counters[depth + 1u]);
-    if (threadIdx.x == 0 && s_hits) atomicAdd(&counters[kHitCounter], s_hits);
     if (alive) { rays_out.org[slot] = o0; rays_out.dir[slot] = o1; rays_out.thr[slot] = o2; rays_out.inv[slot] = o3; }
     const uint32_t sslot = block_reserve(want_shadow, bs, &counters[kShadowCount + depth]);
     if (want_shadow) { shadow.org[sslot] = q0; shadow.dir[sslot] = q1; shadow.thr[sslot] = q2; shadow.inv[sslot] = q3; }
+    }
+    if (threadIdx.x == 0 && s_hits) atomicAdd(&counters[kHitCounter], s_hits);      // block_reserve's barriers order the LDS adds before this read
 }
 
 __global__ void __launch_bounds__(256) k_shadow_resolve(uint32_t depth, RayQueue shadow, const HitOut *__restrict__ hits,
                                                         const uint32_t *__restrict__ counters, float4 *__restrict__ results)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= counters[kShadowCount + depth]) return;
-    if (hits[i].tri != 0xFFFFFFFFu) return;        // occluded
-    const uint32_t path = __float_as_uint(shadow.org[i].w);
-    const float4 c = shadow.thr[i];
-    float4 cur = results[path];
-    cur.x = cur.x + c.x; cur.y = cur.y + c.y; cur.z = cur.z + c.z;
-    results[path] = cur;
+    const uint32_t n = counters[kShadowCount + depth];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {      // capped grid
+        if (hits[i].tri != 0xFFFFFFFFu) continue;        // occluded
+        const uint32_t path = __float_as_uint(shadow.org[i].w);      // one occlusion ray per path and bounce: no two lanes share a path
+        const float4 c = shadow.thr[i];
+        float4 cur = results[path];
+        cur.x = cur.x + c.x; cur.y = cur.y + c.y; cur.z = cur.z + c.z;
+        results[path] = cur;
+    }
 }
 
 // ---------------------------------------------------------------- resolve
@@ -956,14 +960,20 @@ uint32_t extend_resident_waves(int device)
     return (uint32_t)per_cu * (uint32_t)cus;
 }
 
+// most blocks a shading launch starts; a block walks tiles beyond that (PTX_SHADE_GRID)
+static uint32_t shade_grid_cap()
+{
+    static const uint32_t cap = [] { const char *e = getenv("PTX_SHADE_GRID"); int v = e ? atoi(e) : 8192; return (uint32_t)(v < 64 ? 64 : v); }();
+    return cap;
+}
+
 void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
                   RayQueue rays_in, const HitOut *hits, uint32_t *counters, uint32_t capacity, RayQueue rays_out,
                   float4 *results)
 {
     uint32_t blocks = (capacity + kShadeBlock - 1u) / kShadeBlock;
     if (!blocks) return;
-    static const uint32_t cap = [] { const char *e = getenv("PTX_SHADE_GRID"); int v = e ? atoi(e) : 8192; return (uint32_t)(v < 64 ? 64 : v); }();
-    blocks = std::min(blocks, cap);
+    blocks = std::min(blocks, shade_grid_cap());
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kShadeBlock), 0, s, sc, f, img, depth, rays_in, hits, counters,
                        capacity, rays_out, results);
 }
@@ -974,6 +984,7 @@ void launch_shade_lit(hipStream_t s, const SceneDev &sc, const FrameDev &f, cons
 {
     uint32_t blocks = (capacity + kShadeBlock - 1u) / kShadeBlock;
     if (!blocks) return;
+    blocks = std::min(blocks, shade_grid_cap());
     hipLaunchKernelGGL(k_shade_lit, dim3(blocks), dim3(kShadeBlock), 0, s, sc, f, img, depth, rays_in, hits, counters,
                        capacity, rays_out, shadow, results);
 }
@@ -983,6 +994,7 @@ void launch_shadow_resolve(hipStream_t s, uint32_t depth, RayQueue shadow, const
 {
     uint32_t blocks = (capacity + 255u) / 256u;
     if (!blocks) return;
+    blocks = std::min(blocks, shade_grid_cap() * 2u);
     hipLaunchKernelGGL(k_shadow_resolve, dim3(blocks), dim3(256), 0, s, depth, shadow, hits, counters, results);
 }
 
