@@ -6,7 +6,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <future>
@@ -25,10 +27,17 @@ struct Node2 {
     uint32_t tfirst = 0, tcount = 0; // triangle range of the whole subtree (contiguous in `order`)
 };
 
+// One triangle as the builder moves it around: box, centroid and index travel together, so that every pass
+// over a range of `prims` is a sequential stream (an index array into separate box / centroid arrays made
+// each pass a random gather: 2 x the build time on the Sponza stand-in).
+struct Prim {
+    Box box;
+    float c[3];
+    uint32_t tri;
+};
+
 struct Builder2 {
-    const Box *tri_box;
-    const float *centroid;            // 3 per triangle
-    std::vector<uint32_t> order;
+    std::vector<Prim> prims;
     std::vector<Node2> nodes;
     std::atomic<uint32_t> n_nodes{0};
 
@@ -42,12 +51,12 @@ struct Builder2 {
         Node2 &n = nodes[node];
         n.tfirst = first; n.tcount = count;
         Box cb; cb.reset(); n.box.reset();
+        const Prim *pr = prims.data();
         for (uint32_t i = first; i < first + count; ++i) {
-            uint32_t t = order[i];
-            n.box.grow(tri_box[t]);
+            n.box.grow(pr[i].box);
             for (int a = 0; a < 3; ++a) {
-                cb.lo[a] = std::min(cb.lo[a], centroid[t * 3 + a]);
-                cb.hi[a] = std::max(cb.hi[a], centroid[t * 3 + a]);
+                cb.lo[a] = std::min(cb.lo[a], pr[i].c[a]);
+                cb.hi[a] = std::max(cb.hi[a], pr[i].c[a]);
             }
         }
         if (count == 1) { n.first = first; n.count = 1; return; }
@@ -62,9 +71,8 @@ struct Builder2 {
             for (int b = 0; b < kBins; ++b) { bins[b].reset(); cnt[b] = 0; }
             float k = kBins / ext;
             for (uint32_t i = first; i < first + count; ++i) {
-                uint32_t t = order[i];
-                int b = std::min(kBins - 1, std::max(0, (int)((centroid[t * 3 + a] - cb.lo[a]) * k)));
-                bins[b].grow(tri_box[t]); cnt[b]++;
+                int b = std::min(kBins - 1, std::max(0, (int)((pr[i].c[a] - cb.lo[a]) * k)));
+                bins[b].grow(pr[i].box); cnt[b]++;
             }
             float right_area[kBins]; uint32_t right_cnt[kBins];
             Box acc; acc.reset(); uint32_t c = 0;
@@ -94,11 +102,11 @@ struct Builder2 {
             float ext = cb.hi[best_axis] - cb.lo[best_axis];
             float k = kBins / ext, lo = cb.lo[best_axis];
             int a = best_axis, bb = best_bin;
-            auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
-                int b = std::min(kBins - 1, std::max(0, (int)((centroid[t * 3 + a] - lo) * k)));
+            auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim &p) {
+                int b = std::min(kBins - 1, std::max(0, (int)((p.c[a] - lo) * k)));
                 return b <= bb;
             });
-            mid = (uint32_t)(it - order.begin());
+            mid = (uint32_t)(it - prims.begin());
             if (mid == first || mid == first + count) mid = first + count / 2;
         }
         uint32_t l = alloc2();
@@ -182,22 +190,38 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
     if (n_tris == 0) return true;
     if (n_tris > 1000000000u) return false;
 
+    static const bool verbose = getenv("PTX_VERBOSE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!verbose) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ptx] build_bvh8 %-10s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     std::vector<Box> tri_box;
     std::vector<uint32_t> order = padded_tri_boxes(verts, n_tris, tri_box, n_threads);
     if (order.empty()) return true;
-    std::vector<float> centroid(n_tris * 3);
-    for (uint32_t t : order)
-        for (int a = 0; a < 3; ++a) centroid[(size_t)t * 3 + a] = 0.5f * tri_box[t].lo[a] + 0.5f * tri_box[t].hi[a];
+    lap("boxes");
 
     Builder2 b2;
-    b2.tri_box = tri_box.data(); b2.centroid = centroid.data();
-    b2.order = std::move(order);
-    uint32_t n = (uint32_t)b2.order.size();
+    uint32_t n = (uint32_t)order.size();
+    b2.prims.resize(n);
+    par_for(n, n_threads, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            Prim &p = b2.prims[i];
+            p.tri = order[i]; p.box = tri_box[p.tri];
+            for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * p.box.lo[a] + 0.5f * p.box.hi[a];
+        }
+    });
     b2.nodes.resize((size_t)2 * n + 2);
     b2.n_nodes = 1;
+    // SAH splits are lopsided: 8 x more subtrees than threads, so that no thread is left with one huge subtree
     int spawn = 0;
     while ((1 << spawn) < std::max(1, n_threads)) ++spawn;
+    if (n_threads > 1) spawn += 3;
+    lap("setup");
     b2.build(0, 0, n, spawn);
+    lap("bvh2");
 
     // ---- collapse to 8-wide ----
     // Which BVH2 nodes become the (up to 8) children of each wide node is chosen by the dynamic
@@ -238,6 +262,7 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
         d.c[1] = d.leaf ? c_leaf : c_internal;
         for (int i = 2; i <= 7; ++i) d.c[i] = std::min(dist[i], d.c[i - 1]);
     }
+    lap("dp");
     // children of the wide node rooted at BVH2 node `n` when it may use `i` slots
     struct Gather {
         const std::vector<Node2> &nodes; const std::vector<Dp> &dp;
@@ -252,82 +277,113 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
         }
     } gather{b2.nodes, dp};
 
-    struct Pending { uint32_t node2; uint32_t depth; };
-    std::vector<Pending> queue;
-    queue.push_back({0u, 1u});
-    out.nodes.resize(1);
-    out.tri_order.reserve(n);
+    // Breadth-first, one level at a time: (1) per node, in parallel: its children and their slots; (2) a serial
+    // prefix over the level: where each node's children and leaf triangles start; (3) per node, in parallel:
+    // the quantised node and its part of the triangle order.  Node indices = breadth-first positions.
+    struct Wide { uint32_t node2; uint32_t kids[8]; int8_t slot_child[8]; uint32_t n_inner, n_leaf_tris, child_base, tri_base; };
+    std::vector<Wide> level(1), next;
+    level[0].node2 = 0;
+    out.nodes.clear();
+    out.tri_order.clear();
     out.level_first.clear();
-    for (size_t qi = 0; qi < queue.size(); ++qi) {
-        const Node2 &src = b2.nodes[queue[qi].node2];
-        uint32_t depth = queue[qi].depth;
-        if (depth > out.depth) out.level_first.push_back((uint32_t)qi);      // breadth-first queue: depths never decrease
-        out.depth = std::max(out.depth, depth);
-
-        uint32_t kids[8]; int nk = 0;
-        if (src.count > 0 || dp[queue[qi].node2].leaf) {
-            kids[nk++] = queue[qi].node2;             // a leaf root becomes the single leaf slot
-        } else {
-            int k = dp[queue[qi].node2].k[8];
-            gather.run(src.left, k, kids, nk);
-            gather.run(src.right, 8 - k, kids, nk);
-        }
-
-        // slot assignment: slot s is visited first by rays whose direction is negative exactly
-        // on the axes whose bit is set in s (bit2 = x, bit1 = y, bit0 = z), so it should hold the
-        // child lying furthest along ds(s) = (+1 where the bit is set, -1 elsewhere).
-        float center[3];
-        for (int a = 0; a < 3; ++a) center[a] = 0.5f * src.box.lo[a] + 0.5f * src.box.hi[a];
-        float cost[8][8];
-        for (int c = 0; c < nk; ++c) {
-            const Box &cbx = b2.nodes[kids[c]].box;
-            float d[3];
-            for (int a = 0; a < 3; ++a) d[a] = (0.5f * cbx.lo[a] + 0.5f * cbx.hi[a]) - center[a];
-            for (int s = 0; s < 8; ++s)
-                cost[c][s] = ((s & 4) ? d[0] : -d[0]) + ((s & 2) ? d[1] : -d[1]) + ((s & 1) ? d[2] : -d[2]);
-        }
-        int slot_child[8]; bool child_done[8] = {false};
-        for (int s = 0; s < 8; ++s) slot_child[s] = -1;
-        for (int it = 0; it < nk; ++it) {
-            float best = -std::numeric_limits<float>::infinity(); int bc = -1, bs = -1;
-            for (int c = 0; c < nk; ++c) {
-                if (child_done[c]) continue;
-                for (int s = 0; s < 8; ++s)
-                    if (slot_child[s] < 0 && cost[c][s] > best) { best = cost[c][s]; bc = c; bs = s; }
+    uint32_t n_nodes_total = 1, n_tris_total = 0;
+    while (!level.empty()) {
+        out.level_first.push_back((uint32_t)out.nodes.size());
+        out.depth++;
+        par_for(level.size(), n_threads, [&](size_t lo, size_t hi) {
+            for (size_t wi = lo; wi < hi; ++wi) {
+                Wide &w = level[wi];
+                const Node2 &src = b2.nodes[w.node2];
+                uint32_t *kids = w.kids; int nk = 0;
+                if (src.count > 0 || dp[w.node2].leaf) {
+                    kids[nk++] = w.node2;             // a leaf root becomes the single leaf slot
+                } else {
+                    int k = dp[w.node2].k[8];
+                    gather.run(src.left, k, kids, nk);
+                    gather.run(src.right, 8 - k, kids, nk);
+                }
+                // slot assignment: slot s is visited first by rays whose direction is negative exactly
+                // on the axes whose bit is set in s (bit2 = x, bit1 = y, bit0 = z), so it should hold the
+                // child lying furthest along ds(s) = (+1 where the bit is set, -1 elsewhere).
+                float center[3];
+                for (int a = 0; a < 3; ++a) center[a] = 0.5f * src.box.lo[a] + 0.5f * src.box.hi[a];
+                float cost[8][8];
+                for (int c = 0; c < nk; ++c) {
+                    const Box &cbx = b2.nodes[kids[c]].box;
+                    float d[3];
+                    for (int a = 0; a < 3; ++a) d[a] = (0.5f * cbx.lo[a] + 0.5f * cbx.hi[a]) - center[a];
+                    for (int s = 0; s < 8; ++s)
+                        cost[c][s] = ((s & 4) ? d[0] : -d[0]) + ((s & 2) ? d[1] : -d[1]) + ((s & 1) ? d[2] : -d[2]);
+                }
+                bool child_done[8] = {false};
+                for (int s = 0; s < 8; ++s) w.slot_child[s] = -1;
+                for (int it = 0; it < nk; ++it) {
+                    float best = -std::numeric_limits<float>::infinity(); int bc = -1, bs = -1;
+                    for (int c = 0; c < nk; ++c) {
+                        if (child_done[c]) continue;
+                        for (int s = 0; s < 8; ++s)
+                            if (w.slot_child[s] < 0 && cost[c][s] > best) { best = cost[c][s]; bc = c; bs = s; }
+                    }
+                    w.slot_child[bs] = (int8_t)bc; child_done[bc] = true;
+                }
+                w.n_inner = 0; w.n_leaf_tris = 0;
+                for (int s = 0; s < 8; ++s) {
+                    int c = w.slot_child[s];
+                    if (c < 0) continue;
+                    if (!dp[kids[c]].leaf) ++w.n_inner; else w.n_leaf_tris += b2.nodes[kids[c]].tcount;
+                }
             }
-            slot_child[bs] = bc; child_done[bc] = true;
+        });
+        size_t level_start = out.nodes.size();
+        n_nodes_total = (uint32_t)(level_start + level.size());
+        size_t n_next = 0;
+        for (Wide &w : level) {
+            w.child_base = n_nodes_total + (uint32_t)n_next; w.tri_base = n_tris_total;
+            n_next += w.n_inner; n_tris_total += w.n_leaf_tris;
         }
-
-        Bvh8Node nd; memset(&nd, 0, sizeof nd);
-        set_node_frame(nd, src.box);
-        nd.child_base = (uint32_t)out.nodes.size();
-        nd.tri_base = (uint32_t)out.tri_order.size();
-        uint32_t tri_off = 0, n_inner = 0;
-        for (int s = 0; s < 8; ++s) {
-            int c = slot_child[s];
-            if (c < 0) continue;
-            const Node2 &ch = b2.nodes[kids[c]];
-            set_child_planes(nd, s, ch.box);
-            if (!dp[kids[c]].leaf) {
-                nd.imask |= (uint8_t)(1u << s);
-                nd.meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
-                ++n_inner;
-            } else {
-                nd.meta[s] = (uint8_t)((((1u << ch.tcount) - 1u) << 5) | tri_off);
-                for (uint32_t i = 0; i < ch.tcount; ++i) out.tri_order.push_back(b2.order[ch.tfirst + i]);
-                tri_off += ch.tcount;
+        out.nodes.resize(level_start + level.size());
+        out.tri_order.resize(n_tris_total);
+        next.assign(n_next, Wide());
+        par_for(level.size(), n_threads, [&](size_t lo, size_t hi) {
+            for (size_t wi = lo; wi < hi; ++wi) {
+                const Wide &w = level[wi];
+                const Node2 &src = b2.nodes[w.node2];
+                Bvh8Node nd; memset(&nd, 0, sizeof nd);
+                set_node_frame(nd, src.box);
+                nd.child_base = w.child_base;
+                nd.tri_base = w.tri_base;
+                uint32_t tri_off = 0, inner = 0;
+                for (int s = 0; s < 8; ++s) {
+                    int c = w.slot_child[s];
+                    if (c < 0) continue;
+                    const Node2 &ch = b2.nodes[w.kids[c]];
+                    set_child_planes(nd, s, ch.box);
+                    if (!dp[w.kids[c]].leaf) {
+                        // internal children in slot order => relative index = popcount(imask below the slot)
+                        nd.imask |= (uint8_t)(1u << s);
+                        nd.meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
+                        next[(size_t)(w.child_base - n_nodes_total) + inner].node2 = w.kids[c];
+                        ++inner;
+                    } else {
+                        nd.meta[s] = (uint8_t)((((1u << ch.tcount) - 1u) << 5) | tri_off);
+                        for (uint32_t i = 0; i < ch.tcount; ++i) out.tri_order[(size_t)w.tri_base + tri_off + i] = b2.prims[ch.tfirst + i].tri;
+                        tri_off += ch.tcount;
+                    }
+                }
+                out.nodes[level_start + wi] = nd;
             }
-        }
-        // internal children in slot order => relative index = popcount(imask below the slot)
-        for (int s = 0; s < 8; ++s) {
-            int c = slot_child[s];
-            if (c < 0 || dp[kids[c]].leaf) continue;
-            queue.push_back({kids[c], depth + 1});
-        }
-        out.nodes.resize(out.nodes.size() + n_inner);
-        out.nodes[qi] = nd;
+        });
+        level.swap(next);
     }
     out.level_first.push_back((uint32_t)out.nodes.size());
+    lap("collapse");
+    if (verbose) {      // FNV-1a of the tree, to compare builder variants
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](const void *p, size_t nb) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < nb; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+        mix(out.nodes.data(), out.nodes.size() * sizeof(Bvh8Node));
+        mix(out.tri_order.data(), out.tri_order.size() * sizeof(uint32_t));
+        fprintf(stderr, "[ptx] build_bvh8 %zu nodes, %zu triangles, hash %016llx\n", out.nodes.size(), out.tri_order.size(), (unsigned long long)h);
+    }
     return true;
 }
 
