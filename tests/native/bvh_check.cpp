@@ -52,6 +52,17 @@ int bvhcheck_refit(void *h, const float *verts, const uint32_t *ids, uint64_t n_
     return 1;
 }
 void bvhcheck_destroy(void *h) { delete (Check *)h; }
+// FNV-1a over the node array, the triangle order and the level table: equal for equal trees
+uint64_t bvhcheck_hash(void *h)
+{
+    Check *c = (Check *)h;
+    uint64_t x = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t nb) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < nb; ++i) { x ^= b[i]; x *= 1099511628211ull; } };
+    mix(c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(Bvh8Node));
+    mix(c->bvh.tri_order.data(), c->bvh.tri_order.size() * sizeof(uint32_t));
+    mix(c->bvh.level_first.data(), c->bvh.level_first.size() * sizeof(uint32_t));
+    return x;
+}
 void bvhcheck_info(void *h, uint64_t *n_nodes, uint64_t *n_tris, uint32_t *depth)
 {
     Check *c = (Check *)h;

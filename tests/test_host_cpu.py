@@ -88,6 +88,8 @@ def bvh_check():
     L.bvhcheck_create.restype = C.c_void_p
     L.bvhcheck_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
     L.bvhcheck_destroy.argtypes = [C.c_void_p]
+    L.bvhcheck_hash.argtypes = [C.c_void_p]
+    L.bvhcheck_hash.restype = C.c_uint64
     L.bvhcheck_refit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
     L.bvhcheck_info.argtypes = [C.c_void_p] * 4
     L.bvhcheck_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_float] + [C.c_void_p] * 5
@@ -285,3 +287,20 @@ def test_native_host_code_under_asan_ubsan(tmp_path):
     r = subprocess.run([exe, str(tmp_path / "img.tmp")] + imgs, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "images decoded" in r.stdout
+
+
+def test_threaded_build_equals_serial_build(oracle, bvh_check):
+    """The builder's parallel parts (subtree tasks, level-parallel collapse) only divide the work: the tree is the
+    serial build's, byte for byte, for any thread count -- on a mesh large enough to spawn tasks and to split levels."""
+    from oracle.gltf_ingest import IngestedScene
+    ing = IngestedScene()
+    ing.import_gltf(os.path.join(ASSETS, "lion_head_2k/lion_head_2k.gltf"), decode_image=lambda p: np.zeros((4, 4, 4), np.uint8))
+    ing.import_gltf(os.path.join(ASSETS, "boulder_01_2k/boulder_01_2k.gltf"), (-2, 0, 0), decode_image=lambda p: np.zeros((4, 4, 4), np.uint8))
+    v, ids = _world_tris(ing, oracle)
+    assert len(v) > 100000
+    hashes = []
+    for threads in (1, 3, 16):
+        h = bvh_check.bvhcheck_create(v.ctypes.data, ids.ctypes.data, len(v), threads)
+        hashes.append(bvh_check.bvhcheck_hash(h))
+        bvh_check.bvhcheck_destroy(h)
+    assert hashes[0] == hashes[1] == hashes[2]
