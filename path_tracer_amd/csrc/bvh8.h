@@ -39,6 +39,7 @@ struct Bvh8 {
     std::vector<uint32_t> tri_order; // leaf order -> input triangle index
     uint32_t depth = 0;              // levels of Bvh8Node below and including the root
     std::vector<uint32_t> level_first; // nodes are stored level by level (breadth first): first node of each level, then nodes.size()
+    double built_sah = 0.0;          // the cost figure refit_bvh8 reports (sum of node half-areas / root half-area), of the built tree
 };
 
 // `verts`: 9 floats per triangle (world space).  Deterministic for a given input.

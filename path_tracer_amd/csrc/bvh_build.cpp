@@ -186,7 +186,7 @@ std::vector<uint32_t> padded_tri_boxes(const float *verts, size_t n_tris, std::v
 
 bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
 {
-    out.nodes.clear(); out.tri_order.clear(); out.depth = 0;
+    out.nodes.clear(); out.tri_order.clear(); out.depth = 0; out.built_sah = 0.0;
     if (n_tris == 0) return true;
     if (n_tris > 1000000000u) return false;
 
@@ -287,6 +287,7 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
     out.tri_order.clear();
     out.level_first.clear();
     uint32_t n_nodes_total = 1, n_tris_total = 0;
+    std::vector<float> node_area;             // half-area of every wide node's box, by node index
     while (!level.empty()) {
         out.level_first.push_back((uint32_t)out.nodes.size());
         out.depth++;
@@ -342,6 +343,7 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
             n_next += w.n_inner; n_tris_total += w.n_leaf_tris;
         }
         out.nodes.resize(level_start + level.size());
+        node_area.resize(out.nodes.size());
         out.tri_order.resize(n_tris_total);
         next.assign(n_next, Wide());
         par_for(level.size(), n_threads, [&](size_t lo, size_t hi) {
@@ -371,11 +373,18 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
                     }
                 }
                 out.nodes[level_start + wi] = nd;
+                node_area[level_start + wi] = src.box.half_area();
             }
         });
         level.swap(next);
     }
     out.level_first.push_back((uint32_t)out.nodes.size());
+    {   // what refit_bvh8 would report for this tree: a node's refitted box is the union of its triangles' padded boxes,
+        // which is the BVH2 node's box (min / max are exact), summed in the same order
+        double area_sum = 0.0;
+        for (float a : node_area) area_sum += (double)a;
+        out.built_sah = node_area[0] > 0.0f ? area_sum / (double)node_area[0] : 0.0;
+    }
     lap("collapse");
     if (verbose) {      // FNV-1a of the tree, to compare builder variants
         uint64_t h = 1469598103934665603ull;

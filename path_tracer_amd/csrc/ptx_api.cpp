@@ -607,8 +607,7 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
         c->scene_ready = false;
         if (!build_bvh8(wv.data(), n_tris, bvh, threads)) return fail(c, PTX_ERR_INVALID, "ptx_set_instances: BVH build failed");
         if (bvh.depth > kMaxBvhDepth) return fail(c, PTX_ERR_CAPACITY, "ptx_set_instances: BVH deeper than the traversal stack");
-        Bvh8 probe = bvh;                     // the cost figure of the fresh tree, by the same routine that refits
-        if (!refit_bvh8(probe, wv.data(), n_tris, &c->built_sah, threads)) c->built_sah = 0.0;
+        c->built_sah = bvh.built_sah;         // the cost figure of the fresh tree, the one a refit of unmoved triangles reports
         c->n_builds++;
     } else {
         c->n_refits++;

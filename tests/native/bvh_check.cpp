@@ -52,6 +52,7 @@ int bvhcheck_refit(void *h, const float *verts, const uint32_t *ids, uint64_t n_
     return 1;
 }
 void bvhcheck_destroy(void *h) { delete (Check *)h; }
+double bvhcheck_built_sah(void *h) { return ((Check *)h)->bvh.built_sah; }
 // FNV-1a over the node array, the triangle order and the level table: equal for equal trees
 uint64_t bvhcheck_hash(void *h)
 {

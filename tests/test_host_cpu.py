@@ -88,6 +88,8 @@ def bvh_check():
     L.bvhcheck_create.restype = C.c_void_p
     L.bvhcheck_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
     L.bvhcheck_destroy.argtypes = [C.c_void_p]
+    L.bvhcheck_built_sah.argtypes = [C.c_void_p]
+    L.bvhcheck_built_sah.restype = C.c_double
     L.bvhcheck_hash.argtypes = [C.c_void_p]
     L.bvhcheck_hash.restype = C.c_uint64
     L.bvhcheck_refit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
@@ -302,5 +304,11 @@ def test_threaded_build_equals_serial_build(oracle, bvh_check):
     for threads in (1, 3, 16):
         h = bvh_check.bvhcheck_create(v.ctypes.data, ids.ctypes.data, len(v), threads)
         hashes.append(bvh_check.bvhcheck_hash(h))
+        # the build's own cost figure is what a refit of the unmoved triangles reports (the rebuild-or-refit rule compares the two)
+        sah = C.c_double()
+        built = bvh_check.bvhcheck_built_sah(h)
+        assert bvh_check.bvhcheck_refit(h, v.ctypes.data, ids.ctypes.data, len(v), C.byref(sah)) == 1
+        assert built > 1.0 and sah.value == built
+        assert bvh_check.bvhcheck_hash(h) == hashes[-1]          # and that refit reproduces the built nodes
         bvh_check.bvhcheck_destroy(h)
     assert hashes[0] == hashes[1] == hashes[2]
