@@ -135,6 +135,9 @@ def test_lit_stress_scene_many_lights(oracle, gpu_ctx_factory):
         if i % 5 == 1:
             ing.material_ext[i]["transmission"] = np.float32(0.7)
             ing.material_ext[i]["ior"] = np.float32(1.33)
+        if i % 3 == 0:
+            # a metallic-roughness map from the linear (even-numbered) textures, beyond the 64 descriptors kept in LDS too
+            ing.material_ext[i]["mr_texture"] = (2 * i) % 70 + 1
     ctx = gpu_ctx_factory()
     upload(ctx, ing, oracle, options=capi.SCENE_WORLD_NORMALS, with_material_ext=True)
     sc = oracle.scene_from_ingest(ing, options=oracle.SCENE_WORLD_NORMALS, with_material_ext=True)
