@@ -56,7 +56,9 @@ def main():
     ap.add_argument("--integrator", default="reference", choices=["reference", "lit"],
                     help="reference: the reference's rchit/rmiss shading (the headline number); lit: the build's "
                          "extension with emissive triangles + next-event estimation + GGX/glass BSDFs (SURVEY 8f.3)")
-    ap.add_argument("--cpu-baseline-spp", type=int, default=2, help="0 disables the CPU leg")
+    ap.add_argument("--cpu-baseline-spp", type=int, default=-1,
+                    help="samples per pixel of the CPU leg; -1 (default): about 8.3 M pixel-samples (4 spp at 1080p, "
+                         "roughly 20 s on 16 cores for Sponza); 0 disables the CPU leg")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the N > 1 path on a box with ONE GPU: every rank renders on device 0 and the "
                          "accumulation reduce goes through host memory over gloo (RCCL refuses two ranks on one device)")
@@ -232,8 +234,9 @@ def main():
 
         cpu = None
         parity = None
-        if args.cpu_baseline_spp > 0:
-            cpu, parity = cpu_baseline(r, wl, assets, W, H, args.cpu_baseline_spp, args.max_depth, args.workload, lit)
+        cpu_spp = args.cpu_baseline_spp if args.cpu_baseline_spp >= 0 else max(1, min(32, round(4 * 1920 * 1080 / (W * H))))
+        if cpu_spp > 0:
+            cpu, parity = cpu_baseline(r, wl, assets, W, H, cpu_spp, args.max_depth, args.workload, lit)
 
         out = {
             "metric": "samples/sec (Mrays/s) Sponza 1080p at 1/2/4/8 MI355X; rel-MSE vs ref",
