@@ -219,3 +219,45 @@ def test_c5_converged_4096spp_rel_mse(oracle, gpu_ctx_factory, standins_ready):
     err8 = rel_mse(combined, want)
     assert err8 <= 1e-3 and err8 < 1e-9, err8
     assert st["samples"] >= W * H * SPP
+
+
+def test_odd_extents_depth_extremes_and_bad_triangles(oracle, gpu_ctx_factory):
+    """Edges of the input space: 1 x 1 and other extents that are no multiple of a wave or a block, max_depth 1 and 32,
+    one sample; and a scene that carries degenerate, non-finite and duplicated triangles (they hit nothing / tie)."""
+    from path_tracer_amd import capi
+    from oracle.gltf_ingest import IngestedScene, MATERIAL_DTYPE, VERTEX_DTYPE, calculate_normals
+    ing = cornell()
+    ctx = gpu_ctx_factory()
+    upload(ctx, ing, oracle)
+    sc = oracle.scene_from_ingest(ing)
+    for (w, h), depth, spp in (((1, 1), 16, 3), ((3, 17), 1, 2), ((65, 33), 32, 2), ((257, 1), 4, 1)):
+        cam = oracle.camera_matrices([0, 1.0, 3.9], oracle.yaw_quat(7.0), np.deg2rad(np.float32(40)), w / h, 0.1, 1000.0)
+        want = sc.render(cam, w, h, spp, SEED, params=oracle.default_params(max_depth=depth))
+        got = gpu_render(ctx, oracle, cam, w, h, spp, params=capi.default_params(max_depth=depth))
+        assert_images_bit_equal(got, want, "cornell %dx%d depth %d" % (w, h, depth))
+
+    bad = IngestedScene()
+    m = np.zeros(1, dtype=MATERIAL_DTYPE)
+    m["base_color"] = [0.8, 0.6, 0.4, 1.0]; m["roughness"] = 0.7
+    mi = bad.add_material(m)
+    p = np.float32([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0],          # a good quad
+                    [0, 0, 1], [0, 0, 1], [0, 0, 1],                          # a point
+                    [-1, 0, 0.5], [0, 0, 0.5], [1, 0, 0.5],                   # collinear
+                    [np.nan, 0, 0.2], [1, 0, 0.2], [0, 1, 0.2],               # NaN vertex
+                    [np.inf, 0, 0.3], [1, 0, 0.3], [0, 1, 0.3],               # infinite vertex
+                    [-0.5, -0.5, 0.25], [0.5, -0.5, 0.25], [0, 0.5, 0.25]])   # a good triangle in front, listed twice below
+    idx = np.uint32([0, 1, 2, 0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 16, 17, 18])
+    v = np.zeros(len(p), dtype=VERTEX_DTYPE)
+    v["position"] = p
+    v["normal"] = [0, 0, 1]
+    geom = bad._geometry_create("bad", v, idx)
+    bad.entities.append((geom, (np.float32([0, 0, 0]), np.float32([0, 0, 0, 1]), np.float32([1, 1, 1])), mi))
+    ctx = gpu_ctx_factory()
+    upload(ctx, bad, oracle)
+    sc = oracle.scene_from_ingest(bad)
+    cam = oracle.camera_matrices([0.1, 0.05, 3.0], oracle.yaw_quat(0), np.deg2rad(np.float32(50)), 1.0, 0.1, 1000.0)
+    want = sc.render(cam, 96, 96, 4, SEED, params=oracle.default_params(max_depth=6))
+    got = gpu_render(ctx, oracle, cam, 96, 96, 4, params=capi.default_params(max_depth=6))
+    assert_images_bit_equal(got, want, "bad triangles")
+    prims = set(np.unique(want["ids"][..., 1]).tolist())
+    assert prims == {0, 1, 6, 0xFFFFFFFF}                 # the quad, the first copy of the front triangle, the sky
