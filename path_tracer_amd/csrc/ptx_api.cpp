@@ -869,7 +869,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
             uint64_t *trav = c->count_traversal ? c->d_totals + 3 : nullptr;
             EventPair e{}, e2{};
             if (c->profiling) { e = get_events(c, 0); HIP_TRY(c, hipEventRecord(e.a, st)); }
-            launch_extend(st, sc, f, rin, ps.d_counters + b, ps.d_counters + kNextBase + b, n_paths, waves, ps.d_hits, trav, false, b == 0);
+            launch_extend(st, sc, f, rin, ps.d_counters + b, ps.d_counters + fetch_heads(b, 0), n_paths, waves, ps.d_hits, trav, false, b == 0);
             if (c->profiling) {
                 HIP_TRY(c, hipEventRecord(e.b, st)); c->events.push_back(e);
                 e2 = get_events(c, 1); HIP_TRY(c, hipEventRecord(e2.a, st));
@@ -887,7 +887,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
                 // occlusion rays of this bounce: any-hit traversal, then the unoccluded contributions join the radiance
                 EventPair e3{};
                 if (c->profiling) { e3 = get_events(c, 0); HIP_TRY(c, hipEventRecord(e3.a, st)); }
-                launch_extend(st, sc, f, shadow_q, ps.d_counters + kShadowCount + b, ps.d_counters + kShadowNext + b, n_paths,
+                launch_extend(st, sc, f, shadow_q, ps.d_counters + kShadowCount + b, ps.d_counters + fetch_heads(b, 1), n_paths,
                               waves, ps.d_hits, nullptr, true);
                 if (c->profiling) { HIP_TRY(c, hipEventRecord(e3.b, st)); c->events.push_back(e3); }
                 launch_shadow_resolve(st, b, shadow_q, ps.d_hits, ps.d_counters, n_paths, ps.d_results);

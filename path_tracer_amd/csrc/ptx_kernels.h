@@ -105,10 +105,18 @@ struct ImagesDev {
 // counters[0 .. max_depth]: live rays entering each bounce; counters[kHitCounter]: hits of the chunk;
 constexpr uint32_t kMaxDepthLimit = 64;
 constexpr uint32_t kHitCounter = kMaxDepthLimit + 1;
-constexpr uint32_t kNextBase = kMaxDepthLimit + 2;      // counters[kNextBase + b]: fetch cursor of bounce b's extend
+constexpr uint32_t kNextBase = kMaxDepthLimit + 2;      // (unused since the fetch cursors became per-XCD heads, kept for the layout)
 constexpr uint32_t kShadowCount = 2 * kMaxDepthLimit + 3; // counters[kShadowCount + b]: occlusion rays queued by bounce b (lit integrator)
 constexpr uint32_t kShadowNext = 3 * kMaxDepthLimit + 4;  // their fetch cursor
-constexpr uint32_t kNumCounters = 4 * kMaxDepthLimit + 5;
+// Fetch cursors of the traversal launches: the ray queue of a launch is cut into kFetchHeads contiguous segments, one head
+// word each, 128 bytes apart (a single word takes ~88 M atomics/s chip-wide; MI355X_MICROARCH.md "dequeue": shard the head
+// per XCD).  A wave pulls from the segment of its XCD (blockIdx % 8) and moves on to the others when that one is empty.
+constexpr uint32_t kFetchHeads = 8;
+constexpr uint32_t kHeadStride = 32;                      // words
+constexpr uint32_t kHeadBase = 4 * kMaxDepthLimit + 5;    // heads of (bounce b, kind k: 0 path rays, 1 occlusion rays) at fetch_heads(b, k)
+constexpr uint32_t kHeadsPerLaunch = kFetchHeads * kHeadStride;
+constexpr uint32_t kNumCounters = kHeadBase + kMaxDepthLimit * 2 * kHeadsPerLaunch;
+inline constexpr uint32_t fetch_heads(uint32_t bounce, uint32_t kind) { return kHeadBase + (bounce * 2u + kind) * kHeadsPerLaunch; }
 
 // traversal stack: entries held in LDS per lane, remainder in private memory
 #ifndef PTX_LDS_STACK

@@ -42,9 +42,10 @@ __global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, Ra
                                                 uint32_t *__restrict__ counters)
 {
     uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p == 0) {
-        counters[0] = n_paths;
-        for (uint32_t i = 1; i < kNumCounters; ++i) counters[i] = 0;
+    if (blockIdx.x == 0) {      // the chunk's counters: queue lengths, hit count, and the fetch heads of the bounces this frame can reach
+        const uint32_t depth = f.max_depth < 1u ? 1u : (f.max_depth < kMaxDepthLimit ? f.max_depth : kMaxDepthLimit);
+        const uint32_t n_clear = fetch_heads(depth, 0);
+        for (uint32_t i = threadIdx.x; i < n_clear; i += 256u) counters[i] = i == 0 ? n_paths : 0u;
     }
     if (p >= n_paths) return;
     uint32_t pix = p % f.n_pixels;
@@ -195,10 +196,16 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
         const uint32_t cap = sched.chunk * sched.chunk_grow;
         if (per_wave > chunk) chunk = (per_wave < cap ? per_wave : cap) & ~63u;
     }
-    // wave-uniform: the queue has been handed out completely.  At most ceil(n / chunk) waves can ever
-    // receive rays: on a short queue (late bounces, small frames) the rest of the grid starts out
-    // "exhausted" and leaves without paying a same-address atomic (~88 M/s chip-wide).
-    bool exhausted = (uint64_t)blockIdx.x * chunk >= n;
+    // The queue is cut into kFetchHeads segments with a head word each; this wave starts on the segment of its XCD
+    // (workgroups are dealt round-robin over the 8 XCDs: speed only, nothing depends on it) and goes round the
+    // others when a segment is empty.  `dead`: segments seen empty (wave-uniform).
+    const uint32_t seg = ((n + kFetchHeads - 1u) / kFetchHeads + 63u) & ~63u;
+    uint32_t cur_seg = blockIdx.x & (kFetchHeads - 1u);
+    uint32_t dead = 0;
+    // wave-uniform: the queue has been handed out completely.  At most ceil(seg / chunk) waves per segment can
+    // ever receive rays: on a short queue (late bounces, small frames) the rest of the grid starts out
+    // "exhausted" and leaves without paying an atomic.
+    bool exhausted = (uint64_t)(blockIdx.x / kFetchHeads) * chunk >= seg || n == 0;
 
     for (;;) {
         unsigned long long idle = __ballot(!active);
@@ -206,12 +213,25 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
             if (kStats) w_refills++;
             for (int pass = 0; pass < 2 && idle != 0ull; ++pass) {
                 if (chunk_next == chunk_end) {
-                    uint32_t base = 0;
-                    if (threadIdx.x == 0) base = atomicAdd(next, chunk);
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    if (base >= n) { exhausted = true; break; }
-                    chunk_next = base;
-                    chunk_end = (n - base < chunk) ? n : base + chunk;
+                    bool got = false;
+                    while (dead != (1u << kFetchHeads) - 1u) {
+                        const uint32_t lo = cur_seg * seg;
+                        if (!(dead & (1u << cur_seg)) && lo < n) {
+                            const uint32_t len = (n - lo < seg) ? n - lo : seg;
+                            uint32_t off = 0;
+                            if (threadIdx.x == 0) off = atomicAdd(next + cur_seg * kHeadStride, chunk);
+                            off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+                            if (off < len) {
+                                chunk_next = lo + off;
+                                chunk_end = (len - off < chunk) ? lo + len : lo + off + chunk;
+                                got = true;
+                                break;
+                            }
+                        }
+                        dead |= 1u << cur_seg;
+                        cur_seg = (cur_seg + 1u) & (kFetchHeads - 1u);
+                    }
+                    if (!got) { exhausted = true; break; }
                 }
                 uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 uint32_t avail = chunk_end - chunk_next;
