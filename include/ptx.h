@@ -158,6 +158,7 @@ typedef struct {
     uint64_t lights;                       /* emissive triangles in the light table */
     uint64_t bvh_builds, bvh_refits;       /* acceleration-structure builds / refits since ptx_create */
     uint64_t bvh_device_refits;            /* of the refits, those done entirely on the GPU */
+    uint64_t tail_launches;                /* chunks whose last bounces ran as one fused launch (since ptx_reset_stats) */
 } ptx_stats;
 
 typedef struct ptx_context ptx_context;

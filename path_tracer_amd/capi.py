@@ -68,7 +68,7 @@ class Stats(C.Structure):
                 ("bvh_bytes", C.c_uint64), ("bvh_depth", C.c_uint32), ("_pad", C.c_uint32),
                 ("nodes_fetched", C.c_uint64), ("tris_tested", C.c_uint64), ("wave_sched", C.c_uint64 * 6),
                 ("shadow_rays", C.c_uint64), ("lights", C.c_uint64), ("bvh_builds", C.c_uint64), ("bvh_refits", C.c_uint64),
-                ("bvh_device_refits", C.c_uint64)]
+                ("bvh_device_refits", C.c_uint64), ("tail_launches", C.c_uint64)]
 
 
 EXPORTS = [

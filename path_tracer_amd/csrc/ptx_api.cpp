@@ -44,6 +44,12 @@ struct PathSet {
     uint32_t *d_counters = nullptr;
     hipEvent_t resolved = nullptr;                   // recorded after the set's latest resolve
     hipEvent_t first_shade = nullptr;                // recorded after the set's latest bounce-0 shading (G-buffer / id image writes)
+    // queue lengths of the set's latest chunk, copied to page-locked host memory behind the chunk (never waited for)
+    uint32_t *h_counts = nullptr;
+    hipEvent_t counts_ready = nullptr;
+    bool counts_pending = false;
+    uint32_t counts_paths = 0, counts_bounces = 0;
+    bool counts_lit = false;
 };
 
 }  // namespace
@@ -82,7 +88,7 @@ struct ptx_context {
     Bvh8 bvh;                                     // host copy of the acceleration structure (refit on instance motion)
     std::vector<ptx_instance> built_instances;    // the list it was built / last refitted for
     double built_sah = 0.0;                       // refit_bvh8's cost figure right after the build
-    uint64_t n_builds = 0, n_refits = 0, n_device_refits = 0;
+    uint64_t n_builds = 0, n_refits = 0, n_device_refits = 0, n_tail_launches = 0;
     uint32_t bvh_depth = 0;
     bool scene_ready = false;
     bool textures_dirty = true;
@@ -97,6 +103,12 @@ struct ptx_context {
     PathSet sets[kMaxSets];
     int n_sets = 2;                         // chunks in flight (PTX_FRAMES_IN_FLIGHT; measured: 2 gives the whole gain, 3 is slower than 2 and 4)
     int next_set = 0;
+    // Queue length per bounce as a fraction of the chunk's paths, from the latest chunk whose counters have arrived: tells
+    // from which bounce on the rest of a chunk is short enough for the fused tail launch.  A guess that only affects speed.
+    bool have_frac = false, frac_lit = false;
+    uint32_t frac_bounces = 0;
+    float live_frac[kMaxDepthLimit] = {};
+    uint32_t tail_rays = 65536;             // PTX_TAIL_RAYS: expected queue length at or below which the tail takes over; 0: never
     hipEvent_t last_resolved = nullptr;     // = sets[k].resolved of the most recent chunk: the next resolve waits for it
     hipEvent_t last_first_shade = nullptr;  // = sets[k].first_shade of the most recent chunk: the next bounce-0 shading waits for it
     uint64_t *d_totals = nullptr;           // rays, hits, samples, nodes fetched, triangles tested
@@ -147,6 +159,8 @@ int ensure_paths(ptx_context *c, PathSet &ps, uint64_t n, bool shadow_queue)
         HIP_TRY(c, hipEventCreateWithFlags(&ps.resolved, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&ps.first_shade, hipEventDisableTiming));
         HIP_TRY(c, hipMalloc((void **)&ps.d_counters, kNumCounters * sizeof(uint32_t)));
+        HIP_TRY(c, hipEventCreateWithFlags(&ps.counts_ready, hipEventDisableTiming));
+        HIP_TRY(c, hipHostMalloc((void **)&ps.h_counts, kMaxDepthLimit * sizeof(uint32_t), hipHostMallocDefault));
     }
     if (n > ps.capacity) {
         HIP_TRY(c, hipStreamSynchronize(ps.stream));
@@ -303,6 +317,7 @@ int ptx_create_with_limits(int device_ordinal, const ptx_limits *limits, ptx_con
     } while (0)
     CREATE_TRY(hipSetDevice(device_ordinal));
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (const char *tr = getenv("PTX_TAIL_RAYS")) { long v = strtol(tr, nullptr, 10); if (v >= 0) c->tail_rays = (uint32_t)std::min<long>(v, 1 << 24); }
     if (const char *fi = getenv("PTX_FRAMES_IN_FLIGHT")) { long v = strtol(fi, nullptr, 10); if (v >= 1 && v <= kMaxSets) c->n_sets = (int)v; }
     CREATE_TRY(hipMalloc((void **)&c->d_totals, kNumTotals * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->d_totals, 0, kNumTotals * sizeof(uint64_t)));
@@ -337,6 +352,8 @@ int ptx_destroy(ptx_context *c)
         dfree(ps.d_counters);
         if (ps.resolved) (void)hipEventDestroy(ps.resolved);
         if (ps.first_shade) (void)hipEventDestroy(ps.first_shade);
+        if (ps.counts_ready) (void)hipEventDestroy(ps.counts_ready);
+        if (ps.h_counts) (void)hipHostFree(ps.h_counts);
         if (ps.stream) (void)hipStreamDestroy(ps.stream);
     }
     dfree(c->d_totals);
@@ -854,6 +871,20 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
         c->next_set = (c->next_set + 1) % c->n_sets;
         if (int r = ensure_paths(c, ps, chunk * npix, lit)) return r;
         hipStream_t st = ps.stream;
+        // queue lengths of finished chunks (any set)
+        for (int si = 0; si < c->n_sets; ++si) {
+            PathSet &q = c->sets[si];
+            if (!q.counts_pending || hipEventQuery(q.counts_ready) != hipSuccess) continue;
+            q.counts_pending = false;
+            c->have_frac = q.counts_paths > 0; c->frac_lit = q.counts_lit; c->frac_bounces = q.counts_bounces;
+            for (uint32_t b = 0; b < q.counts_bounces && q.counts_paths; ++b)
+                c->live_frac[b] = (float)q.h_counts[b] / (float)q.counts_paths;
+        }
+        // the bounce from which the fused tail launch takes the chunk to its end (reference integrator, uninstrumented runs)
+        uint32_t tail_at = bounces;
+        if (c->tail_rays && !lit && !c->count_traversal && c->have_frac && !c->frac_lit && c->frac_bounces == bounces)
+            for (uint32_t b = 1; b < bounces; ++b)
+                if (1.5 * (double)c->live_frac[b] * (double)n_paths <= (double)c->tail_rays) { tail_at = b; break; }
         // Frame-sized chunks (<= 4 Mi paths) with another chunk in flight: half the resident waves each, so that the two
         // traversal kernels share the chip instead of queueing behind each other's persistent grid (1080p frame
         // 8.16 -> 7.74 ms; 16-spp batches want the full grid: 327 vs 302 Msamples/s)
@@ -869,6 +900,12 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
             uint64_t *trav = c->count_traversal ? c->d_totals + 3 : nullptr;
             EventPair e{}, e2{};
             if (c->profiling) { e = get_events(c, 0); HIP_TRY(c, hipEventRecord(e.a, st)); }
+            if (b == tail_at) {
+                launch_tail(st, sc, f, b, rin, ps.d_counters, n_paths, ps.d_results);
+                c->n_tail_launches++;
+                if (c->profiling) { HIP_TRY(c, hipEventRecord(e.b, st)); c->events.push_back(e); }
+                break;
+            }
             launch_extend(st, sc, f, rin, ps.d_counters + b, ps.d_counters + fetch_heads(b, 0), n_paths, waves, ps.d_hits, trav, false, b == 0);
             if (c->profiling) {
                 HIP_TRY(c, hipEventRecord(e.b, st)); c->events.push_back(e);
@@ -899,6 +936,11 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
         launch_accumulate_stats(st, ps.d_counters, bounces, (uint64_t)n_paths, c->d_totals);
         HIP_TRY(c, hipEventRecord(ps.resolved, st));
         c->last_resolved = ps.resolved;
+        if (c->tail_rays) {
+            HIP_TRY(c, hipMemcpyAsync(ps.h_counts, ps.d_counters, bounces * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipEventRecord(ps.counts_ready, st));
+            ps.counts_pending = true; ps.counts_paths = n_paths; ps.counts_bounces = bounces; ps.counts_lit = lit;
+        }
         if (c->profiling) { HIP_TRY(c, hipEventRecord(whole.b, st)); c->events.push_back(whole); }
     }
     HIP_TRY(c, hipGetLastError());
@@ -1008,6 +1050,7 @@ int ptx_get_stats(ptx_context *c, ptx_stats *s)
     s->bvh_depth = c->bvh_depth;
     s->shadow_rays = t[11]; s->lights = c->n_lights;
     s->bvh_builds = c->n_builds; s->bvh_refits = c->n_refits; s->bvh_device_refits = c->n_device_refits;
+    s->tail_launches = c->n_tail_launches;
     return PTX_OK;
 }
 
@@ -1019,6 +1062,7 @@ int ptx_reset_stats(ptx_context *c)
     drain_events(c);
     HIP_TRY(c, hipMemset(c->d_totals, 0, kNumTotals * sizeof(uint64_t)));
     c->extend_ms = c->shade_ms = c->total_ms = 0; c->extend_launches = 0;
+    c->n_tail_launches = 0;
     return PTX_OK;
 }
 

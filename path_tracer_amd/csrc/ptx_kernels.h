@@ -132,6 +132,9 @@ void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, RayQueu
                    uint32_t *next, uint32_t capacity, uint32_t max_waves, HitOut *hits,
                    uint64_t *trav_totals /* NULL: uninstrumented */, bool any_hit = false, bool primary = false);
 uint32_t extend_resident_waves(int device);
+// every remaining bounce of the rays queued for bounce `depth0` (count in counters[depth0]), reference integrator
+void launch_tail(hipStream_t s, const SceneDev &sc, const FrameDev &f, uint32_t depth0, RayQueue rays, uint32_t *counters,
+                 uint32_t capacity, float4 *results);
 void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
                   RayQueue rays_in, const HitOut *hits, uint32_t *counters, uint32_t capacity, RayQueue rays_out,
                   float4 *results);

@@ -587,6 +587,115 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
     }
 }
 
+// ---------------------------------------------------------------- tail: the last bounces of a chunk in one launch
+// The late bounces of a shallow scene are queues of a few hundred rays.  A traversal launch over such a queue is the
+// dependent chain of its slowest ray on an otherwise idle chip (29 ... 90 us measured), and a frame pays it once per
+// bounce.  From the bounce where the host expects a short queue (the lengths of the latest finished chunk: a guess that
+// only affects speed) one launch takes every remaining ray to the end of its path: a lane owns a path, walks the tree
+// for itself (Traversal::step, the scalar form of k_extend's walk: closest hit with the same tie-break, so the same
+// hit) and shades it with k_shade's expression trees.  All chains of all remaining bounces then run side by side.
+// Reference integrator only; bounce 0 (G-buffers, ids) never comes here.
+__global__ void __launch_bounds__(64) k_tail(SceneDev sc, FrameDev f, uint32_t depth0, RayQueue rays,
+                                             uint32_t *__restrict__ counters, float4 *__restrict__ results)
+{
+    __shared__ float s_lut[256];
+    __shared__ TexDesc s_tex[kLdsTextures];
+    __shared__ uint2 s_stack[kLdsStack * 64];
+    const uint32_t n = counters[depth0];
+    if (blockIdx.x * 64u >= n) return;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t w = lane; w < 256u; w += 64u) s_lut[w] = sc.srgb_lut[w];
+    {
+        const uint32_t nw = (sc.n_textures < kLdsTextures ? sc.n_textures : kLdsTextures) * (uint32_t)(sizeof(TexDesc) / 4);
+        for (uint32_t w = lane; w < nw; w += 64u)
+            reinterpret_cast<uint32_t *>(s_tex)[w] = reinterpret_cast<const uint32_t *>(sc.textures)[w];
+    }
+    __syncthreads();
+    uint2 ovf_store[kOvfStack];
+    LaneStack st;
+    st.lds = (lds_uint2 *)s_stack + lane;      // kExtendBlock == 64: the column stride of LaneStack
+    st.ovf = (prv_uint2 *)ovf_store;
+    st.sp = 0;
+    uint32_t n_hits = 0;
+    for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {
+        const uint32_t i = base + lane;
+        bool alive = i < n;
+        f3 ro = mk3(0.0f, 0.0f, 0.0f), rd = ro, thr = ro;
+        uint32_t path = 0, uv_state = 0;
+        if (alive) {
+            const float4 r0 = rays.org[i], r1 = rays.dir[i], r2 = rays.thr[i];
+            ro = mk3(r0.x, r0.y, r0.z); rd = mk3(r1.x, r1.y, r1.z); thr = mk3(r2.x, r2.y, r2.z);
+            path = __float_as_uint(r0.w); uv_state = __float_as_uint(r1.w);
+        }
+        const uint32_t sample = path / f.n_pixels;
+        const uint32_t acc = f.mean_base + sample;
+        for (uint32_t depth = depth0; ; ++depth) {
+            const unsigned long long live = __ballot(alive);
+            if (live == 0ull) break;
+            // the queue lengths of the bounces that never get a queue: ptx_get_stats counts rays from them
+            if (depth > depth0 && lane == 0) atomicAdd(&counters[depth], (uint32_t)__popcll(live));
+            if (!alive) continue;
+            Traversal<LaneStack, false> tr;
+            tr.ng_mask = 0; tr.tg_mask = 0;
+            if (tr.init(sc.n_nodes, ro, rd, f.t_min, f.t_max, st))
+                while (!tr.step(sc.nodes, sc.tris, st)) {}
+            const uint32_t tri = tr.hit.tri;
+            f3 att, new_o = ro, new_d = rd;
+            int done;
+            if (tri == 0xFFFFFFFFu) {
+                att = sky_color(rd);                                             // rmiss.glsl:18-34
+                done = 1;
+            } else {
+                ++n_hits;
+                const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri);
+                const float4 t0 = sp[0], t1 = sp[1], t2 = sp[2], s0 = sp[3], s1 = sp[4], s2 = sp[5], s3 = sp[6], s4 = sp[7];
+                // rchit.glsl:160-254, the expression trees of k_shade
+                f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
+                float hu, hv;
+                tri_uv(ro, rd, mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), hu, hv);
+                float bx = 1.0f - hu - hv, by = hu, bz = hv;
+                f3 normal = normalize((n0 * bx + n1 * by) + n2 * bz);
+                float tu = (s2.y * bx + s2.w * by) + s3.y * bz;
+                float tv = (s2.z * bx + s3.x * by) + s3.z * bz;
+                f3 world_pos = ro + rd * tr.hit.t;
+                f3 albedo;
+                const uint32_t tex = __float_as_uint(t0.w);
+                if (tex != 0xFFFFFFFFu) {
+                    if (tex < kLdsTextures) albedo = sample_texture(s_tex[tex], s_lut, tu, tv);
+                    else albedo = sample_texture(sc.textures[tex], s_lut, tu, tv);
+                    if (f.tex_times_factor) albedo = albedo * mk3(t2.w, s3.w, s4.x);
+                } else {
+                    albedo = mk3(t2.w, s3.w, s4.x);
+                }
+                float roughness = t1.w;
+                float k2 = 2.0f * dot(normal, rd);
+                f3 reflected = rd - normal * k2;
+                f3 rr = normalize(cosine_hemisphere_sample(uv_state, depth, acc + f.rng_offset, f.seed, normal));
+                float om = 1.0f - roughness;
+                f3 scatter = reflected * om + rr * roughness;
+                if (dot(scatter, normal) <= 0.0f) {
+                    done = 1;
+                    att = mk3(0.0f, 0.0f, 0.0f);
+                } else {
+                    done = 0;
+                    att = albedo;
+                }
+                new_o = world_pos + normal * f.normal_eps;
+                new_d = scatter;
+            }
+            thr = thr * att;                                                     // rgen.glsl:80
+            if (done == 1 || depth + 1u >= f.max_depth) {                        // rgen.glsl:101-103
+                results[path] = make_float4(thr.x, thr.y, thr.z, 1.0f);
+                alive = false;
+            } else {
+                ro = new_o; rd = new_d;
+            }
+        }
+    }
+    const uint32_t h = wave_inclusive_sum(n_hits);       // lane 63 holds the wave's total
+    if (lane == 63u && h) atomicAdd(&counters[kHitCounter], h);
+}
+
 // ---------------------------------------------------------------- shade, lit integrator
 // Build extension: the stage that replaces k_shade when params.integrator is
 // PTX_INTEGRATOR_LIT.  Specification: oracle/pt_oracle.c raygen_pixel_lit -- same expression trees, so
@@ -996,6 +1105,14 @@ void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const Im
     blocks = std::min(blocks, shade_grid_cap());
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kShadeBlock), 0, s, sc, f, img, depth, rays_in, hits, counters,
                        capacity, rays_out, results);
+}
+
+void launch_tail(hipStream_t s, const SceneDev &sc, const FrameDev &f, uint32_t depth0, RayQueue rays, uint32_t *counters,
+                 uint32_t capacity, float4 *results)
+{
+    uint32_t blocks = std::min((capacity + 63u) / 64u, 4096u);
+    if (!blocks) return;
+    hipLaunchKernelGGL(k_tail, dim3(blocks), dim3(64), 0, s, sc, f, depth0, rays, counters, results);
 }
 
 void launch_shade_lit(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,

@@ -261,3 +261,32 @@ def test_odd_extents_depth_extremes_and_bad_triangles(oracle, gpu_ctx_factory):
     assert_images_bit_equal(got, want, "bad triangles")
     prims = set(np.unique(want["ids"][..., 1]).tolist())
     assert prims == {0, 1, 6, 0xFFFFFFFF}                 # the quad, the first copy of the front triangle, the sky
+
+
+def test_fused_tail_launch_equals_bounce_by_bounce(oracle, monkeypatch):
+    """From the second chunk on a context knows how short the late queues are and runs the last bounces as one fused
+    launch (a lane per path: scalar traversal + the shading of k_shade).  Image, ids and the ray / hit counts must equal
+    the oracle's and the bounce-by-bounce schedule's (PTX_TAIL_RAYS=0), for single frames, batches and a textured scene."""
+    from helpers import lion_boulder
+    from path_tracer_amd import capi
+    for ing, pos, fov, size in ((cornell(), [0, 1.0, 3.9], 40, (160, 120)), (lion_boulder(), [-1.5, 1.0, 5.0], 70, (192, 108))):
+        sc = oracle.scene_from_ingest(ing)
+        w, h = size
+        cam = oracle.camera_matrices(pos, oracle.yaw_quat(0), np.deg2rad(np.float32(fov)), w / h, 0.1, 1000.0)
+        want = sc.render(cam, w, h, 6, SEED, params=oracle.default_params(max_depth=16))
+        outs = {}
+        for tail in (16384, 0):
+            monkeypatch.setenv("PTX_TAIL_RAYS", str(tail))
+            ctx = capi.Context(0)
+            upload(ctx, ing, oracle)
+            gpu_render(ctx, oracle, cam, w, h, 2, params=capi.default_params(max_depth=16))       # learns the queue lengths
+            ctx.synchronize()
+            ctx.reset_stats()
+            got = gpu_render(ctx, oracle, cam, w, h, 6, params=capi.default_params(max_depth=16), batch=(tail == 0))
+            st = ctx.stats()
+            assert_images_bit_equal(got, want, "tail %d" % tail)
+            assert st["rays"] == want["stats"]["rays"] and st["hits"] == want["stats"]["hits"] and st["samples"] == want["stats"]["samples"]
+            assert (st["tail_launches"] > 0) == (tail > 0), st["tail_launches"]
+            outs[tail] = got
+            ctx.close()
+        assert_images_bit_equal(outs[16384], outs[0], "tail vs bounce by bounce")
