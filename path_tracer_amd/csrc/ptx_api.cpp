@@ -874,7 +874,8 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
         // queue lengths of finished chunks (any set)
         for (int si = 0; si < c->n_sets; ++si) {
             PathSet &q = c->sets[si];
-            if (!q.counts_pending || hipEventQuery(q.counts_ready) != hipSuccess) continue;
+            if (!q.counts_pending) continue;
+            if (hipEventQuery(q.counts_ready) != hipSuccess) { (void)hipGetLastError(); continue; }   // "not ready" is no error: do not leave it for the check at the end
             q.counts_pending = false;
             c->have_frac = q.counts_paths > 0; c->frac_lit = q.counts_lit; c->frac_bounces = q.counts_bounces;
             for (uint32_t b = 0; b < q.counts_bounces && q.counts_paths; ++b)
