@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, Ra
 
     rays.org[p] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(p));
     rays.dir[p] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(hash2(f2u(uvx), f2u(uvy))));
-    rays.thr[p] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);   // rgen.glsl:62
+    // rgen.glsl:62: the throughput of a camera ray is (1, 1, 1) -- not written; the bounce-0 shading stages know it
     float ix, iy, iz;
     uint32_t oct = ray_slab_setup(origin, dir, ix, iy, iz);
     rays.inv[p] = make_float4(ix, iy, iz, __uint_as_float(oct));
@@ -455,7 +455,8 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
     float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
     float2 hr = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
     if (i < capacity) {
-        r0 = rays_in.org[i]; r1 = rays_in.dir[i]; r2 = rays_in.thr[i];
+        r0 = rays_in.org[i]; r1 = rays_in.dir[i];
+        r2 = depth == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : rays_in.thr[i];      // camera rays: rgen.glsl:62, never stored
         hr = *reinterpret_cast<const float2 *>(hits + i);
     }
     const bool valid = i < capacity && i < n_live;
@@ -755,7 +756,8 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
     float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
     float2 hr = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
     if (i < capacity) {
-        r0 = rays_in.org[i]; r1 = rays_in.dir[i]; r2 = rays_in.thr[i];
+        r0 = rays_in.org[i]; r1 = rays_in.dir[i];
+        r2 = depth == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : rays_in.thr[i];      // camera rays: rgen.glsl:62, never stored
         hr = *reinterpret_cast<const float2 *>(hits + i);
     }
     const bool valid = i < capacity && i < n_live;
