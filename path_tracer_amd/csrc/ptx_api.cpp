@@ -852,6 +852,10 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
     ImagesDev img; img.albedo = c->d_albedo; img.normal = c->d_normal; img.depth = c->d_depth; img.ids = c->d_ids;
     FrameDev f;
     f.cam = *cam;
+    {   // rgen.glsl:30 origin = view_inverse * vec4(0, 0, 0, 1): c0*x + c1*y + c2*z + c3*w summed left to right, as the oracle does
+        const float *m = cam->view_inverse;
+        for (int a = 0; a < 3; ++a) f.cam_origin[a] = ((m[a] * 0.0f + m[4 + a] * 0.0f) + m[8 + a] * 0.0f) + m[12 + a] * 1.0f;
+    }
     f.width = c->width; f.height = c->height; f.n_pixels = (uint32_t)npix;
     f.seed = u->seed; f.rng_offset = p.rng_sample_offset;
     f.max_depth = p.max_depth; f.t_min = p.t_min; f.t_max = p.t_max; f.normal_eps = p.normal_eps;

@@ -96,6 +96,8 @@ struct FrameDev {
     uint32_t max_depth;
     float t_min, t_max, normal_eps, z_near, z_far;
     uint32_t tex_times_factor; // PTX_SCENE_TEXTURE_TIMES_FACTOR
+    float cam_origin[3];       // rgen.glsl:30 view_inverse * (0,0,0,1), evaluated once on the host (same expression, no contraction): the
+                               // origin of every camera ray -- k_raygen does not store it, the bounce-0 stages take it from here
 };
 
 struct ImagesDev {

@@ -55,12 +55,12 @@ __global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, Ra
     float uvx = pcx / (float)f.width, uvy = pcy / (float)f.height;
     float dx = uvx * 2.0f - 1.0f, dy = uvy * 2.0f - 1.0f;
     // rgen.glsl:30-34
-    f3 origin = mat4_mul(f.cam.view_inverse, 0.0f, 0.0f, 0.0f, 1.0f);
+    f3 origin = mk3(f.cam_origin[0], f.cam_origin[1], f.cam_origin[2]);
     f3 target = mat4_mul(f.cam.proj_inverse, dx, dy, 1.0f, 1.0f);
     f3 tn = normalize(target);
     f3 dir = normalize(mat4_mul(f.cam.view_inverse, tn.x, tn.y, tn.z, 0.0f));
 
-    rays.org[p] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(p));
+    // the origin plane (camera position, path index = queue index) is not written either: bounce 0 derives it
     rays.dir[p] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(hash2(f2u(uvx), f2u(uvy))));
     // rgen.glsl:62: the throughput of a camera ray is (1, 1, 1) -- not written; the bounce-0 shading stages know it
     float ix, iy, iz;
@@ -115,7 +115,11 @@ struct LaneStack {
 };
 
 // wave-uniform scheduling thresholds (lane counts) and the ray-fetch chunk
-struct ExtendSched { int refill, tri_min, flush_min; uint32_t chunk, chunk_grow; };
+struct ExtendSched {
+    int refill, tri_min, flush_min; uint32_t chunk, chunk_grow;
+    uint32_t primary;       // camera rays: origin = cam_o, path index = queue index (k_raygen stores neither)
+    float cam_o[3];
+};
 
 #ifndef PTX_EXTEND_WAVES_PER_EU
 #define PTX_EXTEND_WAVES_PER_EU 7
@@ -237,7 +241,8 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                 uint32_t avail = chunk_end - chunk_next;
                 if (!active && rank < avail) {
                     uint32_t i = chunk_next + rank;
-                    float4 r0 = rays.org[i], r3 = rays.inv[i];
+                    const float4 r3 = rays.inv[i];
+                    const float4 r0 = sched.primary ? make_float4(sched.cam_o[0], sched.cam_o[1], sched.cam_o[2], __uint_as_float(i)) : rays.org[i];
                     bool go = tr.init_prepared(sc.n_nodes, mk3(r0.x, r0.y, r0.z), r3.x, r3.y, r3.z, __float_as_uint(r3.w), t_min, t_max, st);
                     next_ni = go ? tr.node_pick(st) : 0xFFFFFFFFu;
                     ray = i;
@@ -455,8 +460,10 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
     float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
     float2 hr = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
     if (i < capacity) {
-        r0 = rays_in.org[i]; r1 = rays_in.dir[i];
-        r2 = depth == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : rays_in.thr[i];      // camera rays: rgen.glsl:62, never stored
+        r1 = rays_in.dir[i];
+        // camera rays: origin, path index (= queue index) and unit throughput (rgen.glsl:62) are never stored
+        r0 = depth == 0 ? make_float4(f.cam_origin[0], f.cam_origin[1], f.cam_origin[2], __uint_as_float(i)) : rays_in.org[i];
+        r2 = depth == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : rays_in.thr[i];
         hr = *reinterpret_cast<const float2 *>(hits + i);
     }
     const bool valid = i < capacity && i < n_live;
@@ -756,8 +763,10 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
     float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
     float2 hr = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
     if (i < capacity) {
-        r0 = rays_in.org[i]; r1 = rays_in.dir[i];
-        r2 = depth == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : rays_in.thr[i];      // camera rays: rgen.glsl:62, never stored
+        r1 = rays_in.dir[i];
+        // camera rays: origin, path index (= queue index) and unit throughput (rgen.glsl:62) are never stored
+        r0 = depth == 0 ? make_float4(f.cam_origin[0], f.cam_origin[1], f.cam_origin[2], __uint_as_float(i)) : rays_in.org[i];
+        r2 = depth == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : rays_in.thr[i];
         hr = *reinterpret_cast<const float2 *>(hits + i);
     }
     const bool valid = i < capacity && i < n_live;
@@ -1059,7 +1068,7 @@ static const ExtendSched &extend_sched()
 {
     static const ExtendSched sched = [] {
         auto knob = [](const char *name, int dflt) { const char *e = getenv(name); int v = e ? atoi(e) : dflt; return v < 1 ? 1 : (v > 64 ? 64 : v); };
-        ExtendSched k; k.refill = knob("PTX_REFILL", 8); k.tri_min = knob("PTX_TRI_MIN", 64); k.flush_min = knob("PTX_FLUSH_MIN", 8);
+        ExtendSched k{}; k.refill = knob("PTX_REFILL", 8); k.tri_min = knob("PTX_TRI_MIN", 64); k.flush_min = knob("PTX_FLUSH_MIN", 8);
         const char *ce = getenv("PTX_CHUNK"); int cv = ce ? atoi(ce) : 128; k.chunk = (uint32_t)(cv < 64 ? 64 : cv);
         k.chunk_grow = (uint32_t)knob("PTX_CHUNK_GROW", 4);
         return k;
@@ -1075,6 +1084,8 @@ void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, RayQueu
     // only the camera rays form long queues of cheap, uniform rays; later bounces keep the small chunk (their rays are
     // heavy-tailed and a large chunk lengthens the kernel's tail: Sponza 16-spp batches lose 0.7 % with it)
     if (!primary) sched.chunk_grow = 1;
+    sched.primary = primary ? 1u : 0u;
+    sched.cam_o[0] = f.cam_origin[0]; sched.cam_o[1] = f.cam_origin[1]; sched.cam_o[2] = f.cam_origin[2];
     uint32_t blocks = std::min((capacity + kExtendBlock - 1u) / kExtendBlock, max_waves);
     if (!blocks) return;
     unsigned long long *tt = reinterpret_cast<unsigned long long *>(trav_totals);
