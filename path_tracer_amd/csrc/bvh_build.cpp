@@ -215,10 +215,12 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
     });
     b2.nodes.resize((size_t)2 * n + 2);
     b2.n_nodes = 1;
-    // SAH splits are lopsided: 8 x more subtrees than threads, so that no thread is left with one huge subtree
+    // SAH splits are lopsided: 2 x more subtrees than threads, so that no thread is left with one huge subtree.  (Every
+    // split above the spawn depth holds a thread until its subtree is done: 2^(spawn + 1) threads at most per build -- eight
+    // ranks building at once on one node stay far below any task limit.)
     int spawn = 0;
     while ((1 << spawn) < std::max(1, n_threads)) ++spawn;
-    if (n_threads > 1) spawn += 3;
+    if (n_threads > 1) spawn += 1;
     lap("setup");
     b2.build(0, 0, n, spawn);
     lap("bvh2");
