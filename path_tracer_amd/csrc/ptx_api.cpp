@@ -903,14 +903,13 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
             RayQueue rin = make_ray_queue(ps.d_rays[b & 1], ps.capacity), rout = make_ray_queue(ps.d_rays[(b & 1) ^ 1], ps.capacity);
             RayQueue shadow_q = make_ray_queue(lit ? ps.d_rays[2] : ps.d_rays[0], ps.capacity);
             uint64_t *trav = c->count_traversal ? c->d_totals + 3 : nullptr;
-            EventPair e{}, e2{};
-            if (c->profiling) { e = get_events(c, 0); HIP_TRY(c, hipEventRecord(e.a, st)); }
-            if (b == tail_at) {
+            if (b == tail_at) {      // (its time shows in total_ms only: extend_ms / shade_ms keep meaning the two kernels)
                 launch_tail(st, sc, f, b, rin, ps.d_counters, n_paths, ps.d_results);
                 c->n_tail_launches++;
-                if (c->profiling) { HIP_TRY(c, hipEventRecord(e.b, st)); c->events.push_back(e); }
                 break;
             }
+            EventPair e{}, e2{};
+            if (c->profiling) { e = get_events(c, 0); HIP_TRY(c, hipEventRecord(e.a, st)); }
             launch_extend(st, sc, f, rin, ps.d_counters + b, ps.d_counters + fetch_heads(b, 0), n_paths, waves, ps.d_hits, trav, false, b == 0);
             if (c->profiling) {
                 HIP_TRY(c, hipEventRecord(e.b, st)); c->events.push_back(e);
