@@ -108,6 +108,7 @@ struct ptx_context {
     bool have_frac = false, frac_lit = false;
     uint32_t frac_bounces = 0;
     float live_frac[kMaxDepthLimit] = {};
+    uint32_t tail_shift = 7;                // ... or below 1/128 of the chunk's paths (PTX_TAIL_SHIFT): big batches hand over earlier
     uint32_t tail_rays = 65536;             // PTX_TAIL_RAYS: expected queue length at or below which the tail takes over; 0: never
     hipEvent_t last_resolved = nullptr;     // = sets[k].resolved of the most recent chunk: the next resolve waits for it
     hipEvent_t last_first_shade = nullptr;  // = sets[k].first_shade of the most recent chunk: the next bounce-0 shading waits for it
@@ -317,6 +318,7 @@ int ptx_create_with_limits(int device_ordinal, const ptx_limits *limits, ptx_con
     } while (0)
     CREATE_TRY(hipSetDevice(device_ordinal));
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (const char *ts = getenv("PTX_TAIL_SHIFT")) { long v = strtol(ts, nullptr, 10); if (v >= 0 && v <= 31) c->tail_shift = (uint32_t)v; }
     if (const char *tr = getenv("PTX_TAIL_RAYS")) { long v = strtol(tr, nullptr, 10); if (v >= 0) c->tail_rays = (uint32_t)std::min<long>(v, 1 << 24); }
     if (const char *fi = getenv("PTX_FRAMES_IN_FLIGHT")) { long v = strtol(fi, nullptr, 10); if (v >= 1 && v <= kMaxSets) c->n_sets = (int)v; }
     CREATE_TRY(hipMalloc((void **)&c->d_totals, kNumTotals * sizeof(uint64_t)));
@@ -889,7 +891,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
         uint32_t tail_at = bounces;
         if (c->tail_rays && !lit && !c->count_traversal && c->have_frac && !c->frac_lit && c->frac_bounces == bounces)
             for (uint32_t b = 1; b < bounces; ++b)
-                if (1.5 * (double)c->live_frac[b] * (double)n_paths <= (double)c->tail_rays) { tail_at = b; break; }
+                if (1.5 * (double)c->live_frac[b] * (double)n_paths <= (double)std::max<uint64_t>(c->tail_rays, n_paths >> c->tail_shift)) { tail_at = b; break; }
         // Frame-sized chunks (<= 4 Mi paths) with another chunk in flight: half the resident waves each, so that the two
         // traversal kernels share the chip instead of queueing behind each other's persistent grid (1080p frame
         // 8.16 -> 7.74 ms; 16-spp batches want the full grid: 327 vs 302 Msamples/s)
