@@ -25,7 +25,7 @@ constexpr int kExtendBlock = 64;    // one wave per workgroup: resources free as
 #ifndef PTX_SHADE_BLOCK
 #define PTX_SHADE_BLOCK 512
 #endif
-constexpr int kShadeBlock = PTX_SHADE_BLOCK;   // one queue-tail atomic per block (a single word takes only ~88 M atomics/s); 512 threads x 74 VGPRs = 6 waves/SIMD
+constexpr int kShadeBlock = PTX_SHADE_BLOCK;   // one queue-tail atomic per block (a single word takes only ~88 M atomics/s); 512 threads x 89 VGPRs = 5 waves/SIMD
 
 __device__ __forceinline__ f3 mat4_mul(const float *m, float x, float y, float z, float w)
 {
@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, Ra
 //    wave runs at the pace of its slowest ray (11 % VALU lane utilisation measured, profiles/r01a).
 //    Rays are handed out in two levels -- a wave reserves a chunk of the queue with one atomic and
 //    refills from that chunk -- because one atomic per refill on a single word saturates at
-//    ~88 M/s chip-wide (MI355X_MICROARCH.md "dequeue").
+//    ~88 M/s chip-wide (MI355X_MICROARCH.md "dequeue"); for the same reason the queue has eight
+//    head words, one per XCD-affine segment, with stealing between them.
 //  * Wave-level triangle queue: a lane that hits leaves does not test their triangles itself (the
 //    triangle code would run for the ~20 of 64 lanes that happen to have one pending, r01e).  The
 //    triangles go to a per-wave FIFO in LDS as (triangle, owner lane) pairs and the owner carries
@@ -84,10 +85,9 @@ __global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, Ra
 //    the owner with ds_bpermute) and successful tests are handed back to their owners.  Closest
 //    hit with the (instance, primitive) tie-break is order-independent, so the image is unchanged;
 //    a ray is complete once its node walk is done and the FIFO head has passed its last pair.
-//  * Nodes are loaded straight into registers: with the queue the kernel is bound by the latency
-//    of its dependent chains, not by VALU issue or cache bandwidth (profiles/r01h notes), so what
-//    pays is occupancy without spills -- 5 waves/SIMD at <= 96 VGPRs (6 waves spill, 7 % slower) and
-//    4.8 KB of LDS per wave.
+//  * Nodes are loaded straight into registers; what pays is occupancy without spills -- 7 waves/SIMD
+//    at 68 VGPRs and 4.8 KB of LDS per wave.  At that occupancy the kernel is bound by VALU issue
+//    (0.97 of the issue slots, profiles/valu.json), no longer by the latency of its dependent chains.
 // Traversal stack of one lane: the first kLdsStack entries in the wave's LDS block (column
 // `lane`), the rest in a private array.  The private array is referenced through a pointer so that
 // `sp` and the LDS column stay in registers (a struct holding the array itself is demoted to
