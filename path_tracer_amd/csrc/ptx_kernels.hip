@@ -81,13 +81,13 @@ __global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, Ra
 //  * Wave-level triangle queue: a lane that hits leaves does not test their triangles itself (the
 //    triangle code would run for the ~20 of 64 lanes that happen to have one pending, r01e).  The
 //    triangles go to a per-wave FIFO in LDS as (triangle, owner lane) pairs and the owner carries
-//    on down the tree; when 64 pairs have collected, ANY lane tests ANY pair (ray fetched from
+//    on down the tree; when enough pairs have collected (48), ANY lane tests ANY pair (ray fetched from
 //    the owner with ds_bpermute) and successful tests are handed back to their owners.  Closest
 //    hit with the (instance, primitive) tie-break is order-independent, so the image is unchanged;
 //    a ray is complete once its node walk is done and the FIFO head has passed its last pair.
 //  * Nodes are loaded straight into registers; what pays is occupancy without spills -- 7 waves/SIMD
 //    at 68 VGPRs and 4.8 KB of LDS per wave.  At that occupancy the kernel is bound by VALU issue
-//    (0.97 of the issue slots, profiles/valu.json), no longer by the latency of its dependent chains.
+//    (the issue slots are saturated, profiles/valu.json), no longer by the latency of its dependent chains.
 // Traversal stack of one lane: the first kLdsStack entries in the wave's LDS block (column
 // `lane`), the rest in a private array.  The private array is referenced through a pointer so that
 // `sp` and the LDS column stay in registers (a struct holding the array itself is demoted to
@@ -1068,7 +1068,7 @@ static const ExtendSched &extend_sched()
 {
     static const ExtendSched sched = [] {
         auto knob = [](const char *name, int dflt) { const char *e = getenv(name); int v = e ? atoi(e) : dflt; return v < 1 ? 1 : (v > 64 ? 64 : v); };
-        ExtendSched k{}; k.refill = knob("PTX_REFILL", 8); k.tri_min = knob("PTX_TRI_MIN", 64); k.flush_min = knob("PTX_FLUSH_MIN", 8);
+        ExtendSched k{}; k.refill = knob("PTX_REFILL", 12); k.tri_min = knob("PTX_TRI_MIN", 48); k.flush_min = knob("PTX_FLUSH_MIN", 8);
         const char *ce = getenv("PTX_CHUNK"); int cv = ce ? atoi(ce) : 128; k.chunk = (uint32_t)(cv < 64 ? 64 : cv);
         k.chunk_grow = (uint32_t)knob("PTX_CHUNK_GROW", 4);
         return k;
