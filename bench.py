@@ -63,13 +63,25 @@ def main():
                     help="rehearsal of the N > 1 path on a box with ONE GPU: every rank renders on device 0 and the "
                          "accumulation reduce goes through host memory over gloo (RCCL refuses two ranks on one device)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only bring up the N ranks, check the world size with one all-reduce and print a JSON line; no "
+                         "GPU is touched when combined with --rehearse-gloo (the CPU test of the launcher path)")
+    ap.add_argument("--verify-reduce", action="store_true",
+                    help="after the timed region rank 0 renders every rank's samples on its own GPU and reports the "
+                         "rel-MSE of the combined image against it (small workloads only)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as typed: this process becomes the launcher.  It has not imported torch and has
+        # made no HIP call; the N ranks run under torch.distributed.run as a CHILD process whose output and exit
+        # code are passed on.
+        raise SystemExit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch
     dist = None
@@ -77,11 +89,28 @@ def main():
         import torch.distributed as dist
         if args.rehearse_gloo:
             local_rank = 0
-            torch.cuda.set_device(0)
+            if not args.launch_check:
+                torch.cuda.set_device(0)
             dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    if args.launch_check:
+        ranks_seen = 1
+        if dist is not None:
+            t = torch.ones(1, dtype=torch.float64, device="cpu" if args.rehearse_gloo else "cuda:%d" % local_rank)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            ranks_seen = int(t.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": args.gpus, "rccl_ranks": ranks_seen,
+                              "backend": "gloo" if args.rehearse_gloo else "nccl"}), flush=True)
+        if ranks_seen != args.gpus:
+            raise SystemExit(1)
+        return
 
     from path_tracer_amd import capi, host, standins
     wl = WORKLOADS[args.workload]
@@ -169,6 +198,28 @@ def main():
     else:
         job_samples, job_rays = float(st["samples"]), float(st["rays"])
 
+    reduce_check = None
+    if args.verify_reduce and rank == 0:
+        # The combined image (now in rank 0's accumulation buffer) against ONE context rendering every rank's slice:
+        # rank g holds the running mean of samples first_sample(g) + [0, accumulated_count) -- the first two frames of a
+        # Renderer are dirty frames (renderer.rs:988-1000) that restart the accumulation, so the count is read back.
+        combined_img = ctx.read_image(capi.IMAGE_ALBEDO)
+        n_acc = int(r.accumulated_count)
+        gcam = host.camera_matrices(wl["pos"], host.yaw_quat(wl["yaw"]), np.deg2rad(np.float32(wl["fov"])), W / H, 0.1, 1000.0)
+        acc = np.zeros((H, W, 4), np.float64)
+        for g in range(world):
+            ctx.resize(W, H)
+            first_g, _ = partition_samples(world * (args.steps + args.warmup) * spp, world, g)
+            ctx.render_batch(capi.Uniforms(1, SEED, 0, 0.1, 100.0, (0, 0, 0)), gcam, n_acc,
+                             capi.default_params(max_depth=args.max_depth, rng_sample_offset=first_g,
+                                                 integrator=capi.INTEGRATOR_LIT if lit else capi.INTEGRATOR_REFERENCE))
+            acc += ctx.read_image(capi.IMAGE_ALBEDO)
+        a = np.asarray(combined_img, np.float64)[..., :3]
+        b = (acc / world)[..., :3]
+        reduce_check = {"samples_per_rank": n_acc, "ranks": world,
+                        "rel_mse_vs_single_context": float(np.mean((a - b) ** 2 / (b * b + 1e-2))),
+                        "max_abs_diff": float(np.max(np.abs(a - b))), "rel_mse_eps": 1e-2}
+
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel (k_extend, BVH traversal): algorithmic bytes per launch ----
@@ -242,7 +293,9 @@ def main():
             "metric": "samples/sec (Mrays/s) Sponza 1080p at 1/2/4/8 MI355X; rel-MSE vs ref",
             "value": round(job_samples / elapsed, 1),
             "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
+            "collective_backend": (None if dist is None else ("gloo (rehearsal, host-staged)" if args.rehearse_gloo else "nccl (RCCL)")),
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -258,6 +311,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity": parity,
+            "reduce_check": reduce_check,
         }
     if dist is not None:
         dist.barrier()
@@ -265,6 +319,21 @@ def main():
     r.close()
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+def launch_ranks(n):
+    """Starts `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child process
+    (one rank per GPU, rendezvous on 127.0.0.1 at a free port), relays its output and returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def lit_emitters(workload, materials):

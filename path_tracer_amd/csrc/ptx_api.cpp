@@ -92,6 +92,8 @@ struct ptx_context {
     uint32_t bvh_depth = 0;
     bool scene_ready = false;
     bool textures_dirty = true;
+    bool materials_dirty = true;                  // a material row or its extension changed since the last host-path build
+    uint32_t n_dev_textures = 0;                  // descriptors in d_textures (textures added later wait for the next host-path build)
 
     // images (renderer.rs:476-531)
     uint32_t width = 0, height = 0;
@@ -112,6 +114,7 @@ struct ptx_context {
     uint32_t tail_rays = 65536;             // PTX_TAIL_RAYS: expected queue length at or below which the tail takes over; 0: never
     hipEvent_t last_resolved = nullptr;     // = sets[k].resolved of the most recent chunk: the next resolve waits for it
     hipEvent_t last_first_shade = nullptr;  // = sets[k].first_shade of the most recent chunk: the next bounce-0 shading waits for it
+    bool counted = false;                   // rccl_context_created has been called for this context
     uint64_t *d_totals = nullptr;           // rays, hits, samples, nodes fetched, triangles tested
 
     // profiling
@@ -237,28 +240,79 @@ void srgb_lut(float *lut)
     }
 }
 
-EventPair get_events(ptx_context *c, int kind)
+// A timing pair from the pool, or a fresh one; `ok` = false when the events could not be created (the launch
+// then simply goes untimed).
+EventPair get_events(ptx_context *c, int kind, bool &ok)
 {
-    EventPair p;
+    EventPair p{};
+    ok = true;
     if (!c->event_pool.empty()) { p = c->event_pool.back(); c->event_pool.pop_back(); }
-    else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
+    else if (hipEventCreate(&p.a) != hipSuccess) { (void)hipGetLastError(); p.a = nullptr; ok = false; }
+    else if (hipEventCreate(&p.b) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(p.a); p.a = p.b = nullptr; ok = false; }
     p.kind = kind;
     return p;
 }
 
+void account_pair(ptx_context *c, const EventPair &p)
+{
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        if (p.kind == 0) { c->extend_ms += ms; c->extend_launches++; }
+        else if (p.kind == 1) c->shade_ms += ms;
+        else c->total_ms += ms;
+    } else {
+        (void)hipGetLastError();
+    }
+}
+
+// every recorded pair; the streams must be idle
 void drain_events(ptx_context *c)
 {
-    for (EventPair &p : c->events) {
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-            if (p.kind == 0) { c->extend_ms += ms; c->extend_launches++; }
-            else if (p.kind == 1) c->shade_ms += ms;
-            else c->total_ms += ms;
-        }
-        c->event_pool.push_back(p);
-    }
+    for (EventPair &p : c->events) { account_pair(c, p); c->event_pool.push_back(p); }
     c->events.clear();
 }
+
+// Profiling left on without ptx_get_stats: the pairs whose second event has completed are read and recycled, so
+// the list stays bounded by the work in flight.
+constexpr size_t kEventCap = 4096;
+void drain_completed_events(ptx_context *c)
+{
+    if (c->events.size() < kEventCap) return;
+    size_t keep = 0;
+    for (size_t i = 0; i < c->events.size(); ++i) {
+        EventPair &p = c->events[i];
+        if (p.b && hipEventQuery(p.b) == hipSuccess) { account_pair(c, p); c->event_pool.push_back(p); }
+        else { (void)hipGetLastError(); c->events[keep++] = p; }
+    }
+    c->events.resize(keep);
+}
+
+// One timed launch: begin() records the first event on `st`, end() the second.  If the events cannot be had the
+// launch goes untimed; a pair that is begun and never ended (an early error return) goes back to the pool.
+struct Timed {
+    ptx_context *c = nullptr; EventPair p{}; bool on = false;
+    Timed() = default;
+    Timed(const Timed &) = delete;
+    Timed &operator=(const Timed &) = delete;
+    ~Timed() { if (on) c->event_pool.push_back(p); }
+    void begin(ptx_context *ctx, int kind, hipStream_t st)
+    {
+        c = ctx;
+        if (!c->profiling) return;
+        bool ok = false;
+        p = get_events(c, kind, ok);
+        if (!ok) return;
+        if (hipEventRecord(p.a, st) != hipSuccess) { (void)hipGetLastError(); c->event_pool.push_back(p); return; }
+        on = true;
+    }
+    void end(hipStream_t st)
+    {
+        if (!on) return;
+        on = false;
+        if (hipEventRecord(p.b, st) != hipSuccess) { (void)hipGetLastError(); c->event_pool.push_back(p); return; }
+        c->events.push_back(p);
+    }
+};
 
 inline void xform_point(const float m[3][4], const float p[3], float out[3])
 {
@@ -302,6 +356,7 @@ int ptx_create_with_limits(int device_ordinal, const ptx_limits *limits, ptx_con
     ptx_context *c = new (std::nothrow) ptx_context;
     if (!c) return fail(nullptr, PTX_ERR_INVALID, "ptx_create: out of host memory");
     c->device = device_ordinal;
+    rccl_context_created(device_ordinal); c->counted = true;
     if (limits) c->limits = *limits; else ptx_default_limits(&c->limits);
     if (const char *tp = getenv("PTX_TARGET_PATHS")) {
         unsigned long long v = strtoull(tp, nullptr, 10);
@@ -360,6 +415,7 @@ int ptx_destroy(ptx_context *c)
     }
     dfree(c->d_totals);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->counted) rccl_context_destroyed(c->device);
     delete c;
     return PTX_OK;
 }
@@ -398,6 +454,7 @@ int ptx_add_material(ptx_context *c, const ptx_material *m, uint32_t *index)
     c->materials.push_back(*m);
     ptx_material_ext e; memset(&e, 0, sizeof e); e.ior = 1.5f;
     c->material_ext.push_back(e);
+    c->materials_dirty = true;
     return PTX_OK;
 }
 
@@ -415,6 +472,7 @@ int ptx_set_material_ext(ptx_context *c, uint32_t index, const ptx_material_ext 
         return fail(c, PTX_ERR_INVALID, "ptx_set_material_ext: mr_texture must be a linear (non-sRGB) texture");
     c->material_ext[index] = *ext;
     c->material_ext[index]._pad[0] = c->material_ext[index]._pad[1] = 0;
+    c->materials_dirty = true;
     return PTX_OK;
 }
 
@@ -493,6 +551,9 @@ static int device_refit(ptx_context *c, const ptx_instance *inst, uint32_t n, bo
         c->cap_refit_inst = n;
     }
     if (int r = sync_all(c)) return r;          // frames in flight read the triangles and nodes that are about to move
+    // from here on the device scene is being moved in place: it is not renderable again until this refit has been
+    // accepted (below) or the host path has rebuilt it (the caller's fallback); an error in between leaves it off
+    c->scene_ready = false;
     RefitState st; refit_state_reset(&st);
     HIP_TRY(c, hipMemcpyAsync(c->d_refit_state, &st, sizeof st, hipMemcpyHostToDevice, c->stream));
     if (n) HIP_TRY(c, hipMemcpyAsync(c->d_refit_inst, ri.data(), (size_t)n * sizeof(RefitInstance), hipMemcpyHostToDevice, c->stream));
@@ -535,6 +596,7 @@ static int device_refit(ptx_context *c, const ptx_instance *inst, uint32_t n, bo
     c->built_instances.assign(inst, inst + n);
     c->n_refits++;
     c->n_device_refits++;
+    c->scene_ready = true;
     ok = true;
     return PTX_OK;
 }
@@ -586,7 +648,10 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
             if ((e.emissive[0] > 0.0f || e.emissive[1] > 0.0f || e.emissive[2] > 0.0f) &&
                 memcmp(inst[i].xform, c->built_instances[i].xform, sizeof inst[i].xform) != 0) emitter_moved = true;
         }
-    if (same_list && c->refit_ready && !emitter_moved && !host_refit_only && c->bvh.level_first.size() >= 2) {
+    // ... and nothing else is waiting for the host path: material rows / extensions edited or textures added since the
+    // last build reach the device (ShadeRec, LitMaterial, light table, texture descriptors) only there
+    if (same_list && c->refit_ready && !emitter_moved && !host_refit_only && !c->materials_dirty && !c->textures_dirty &&
+        c->bvh.level_first.size() >= 2) {
         bool ok = false;
         if (int r = device_refit(c, inst, n, ok)) return r;
         lap("dev refit");
@@ -772,12 +837,15 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
     c->built_options = c->scene_options;
     if (c->textures_dirty) {
         dfree(c->d_textures);
+        c->n_dev_textures = 0;
         if (!c->textures.empty()) {
             HIP_TRY(c, hipMalloc((void **)&c->d_textures, c->textures.size() * sizeof(TexDesc)));
             HIP_TRY(c, hipMemcpy(c->d_textures, c->textures.data(), c->textures.size() * sizeof(TexDesc), hipMemcpyHostToDevice));
+            c->n_dev_textures = (uint32_t)c->textures.size();
         }
         c->textures_dirty = false;
     }
+    c->materials_dirty = false;
     // inputs of the device refit: per leaf triangle its instance and vertices, the shared vertex buffer, scratch boxes
     if (!refitted) {
         c->refit_ready = false;
@@ -850,7 +918,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
     SceneDev sc;
     sc.lit_materials = c->d_lit_materials; sc.lights = c->d_lights; sc.light_cdf = c->d_light_cdf; sc.n_lights = c->n_lights;
     sc.nodes = c->d_nodes; sc.n_nodes = c->n_nodes; sc.tris = c->d_tris; sc.shade = c->d_shade;
-    sc.textures = c->d_textures; sc.n_textures = (uint32_t)c->textures.size(); sc.srgb_lut = c->d_lut;
+    sc.textures = c->d_textures; sc.n_textures = c->n_dev_textures; sc.srgb_lut = c->d_lut;
     ImagesDev img; img.albedo = c->d_albedo; img.normal = c->d_normal; img.depth = c->d_depth; img.ids = c->d_ids;
     FrameDev f;
     f.cam = *cam;
@@ -896,8 +964,9 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
         // traversal kernels share the chip instead of queueing behind each other's persistent grid (1080p frame
         // 8.16 -> 7.74 ms; 16-spp batches want the full grid: 327 vs 302 Msamples/s)
         const uint32_t waves = (c->n_sets >= 2 && n_paths <= (4u << 20)) ? std::max(256u, c->extend_waves / 2u) : c->extend_waves;
-        EventPair whole{};
-        if (c->profiling) { whole = get_events(c, 2); HIP_TRY(c, hipEventRecord(whole.a, st)); }
+        drain_completed_events(c);
+        Timed whole;
+        whole.begin(c, 2, st);
         f.mean_base = u->accumulated_count + s0;
         f.ids_sample = (s0 == 0) ? 0u : 0xFFFFFFFFu;
         launch_raygen(st, f, n_paths, make_ray_queue(ps.d_rays[0], ps.capacity), ps.d_counters);
@@ -910,29 +979,27 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
                 c->n_tail_launches++;
                 break;
             }
-            EventPair e{}, e2{};
-            if (c->profiling) { e = get_events(c, 0); HIP_TRY(c, hipEventRecord(e.a, st)); }
+            Timed e, e2;
+            e.begin(c, 0, st);
             launch_extend(st, sc, f, rin, ps.d_counters + b, ps.d_counters + fetch_heads(b, 0), n_paths, waves, ps.d_hits, trav, false, b == 0);
-            if (c->profiling) {
-                HIP_TRY(c, hipEventRecord(e.b, st)); c->events.push_back(e);
-                e2 = get_events(c, 1); HIP_TRY(c, hipEventRecord(e2.a, st));
-            }
+            e.end(st);
             if (b == 0 && c->last_first_shade && c->last_first_shade != ps.first_shade)
                 HIP_TRY(c, hipStreamWaitEvent(st, c->last_first_shade, 0));
+            e2.begin(c, 1, st);
             if (!lit) {
                 launch_shade(st, sc, f, img, b, rin, ps.d_hits, ps.d_counters, n_paths, rout, ps.d_results);
             } else {
                 launch_shade_lit(st, sc, f, img, b, rin, ps.d_hits, ps.d_counters, n_paths, rout, shadow_q, ps.d_results);
             }
             if (b == 0) { HIP_TRY(c, hipEventRecord(ps.first_shade, st)); c->last_first_shade = ps.first_shade; }
-            if (c->profiling) { HIP_TRY(c, hipEventRecord(e2.b, st)); c->events.push_back(e2); }
+            e2.end(st);
             if (lit && c->n_lights) {
                 // occlusion rays of this bounce: any-hit traversal, then the unoccluded contributions join the radiance
-                EventPair e3{};
-                if (c->profiling) { e3 = get_events(c, 0); HIP_TRY(c, hipEventRecord(e3.a, st)); }
+                Timed e3;
+                e3.begin(c, 0, st);
                 launch_extend(st, sc, f, shadow_q, ps.d_counters + kShadowCount + b, ps.d_counters + fetch_heads(b, 1), n_paths,
                               waves, ps.d_hits, nullptr, true);
-                if (c->profiling) { HIP_TRY(c, hipEventRecord(e3.b, st)); c->events.push_back(e3); }
+                e3.end(st);
                 launch_shadow_resolve(st, b, shadow_q, ps.d_hits, ps.d_counters, n_paths, ps.d_results);
             }
         }
@@ -947,7 +1014,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
             HIP_TRY(c, hipEventRecord(ps.counts_ready, st));
             ps.counts_pending = true; ps.counts_paths = n_paths; ps.counts_bounces = bounces; ps.counts_lit = lit;
         }
-        if (c->profiling) { HIP_TRY(c, hipEventRecord(whole.b, st)); c->events.push_back(whole); }
+        whole.end(st);
     }
     HIP_TRY(c, hipGetLastError());
     return PTX_OK;

@@ -1,10 +1,13 @@
 // ptx_rccl.cpp -- ptx_reduce_accumulation: sum the RGBA32F accumulation buffers of one context
 // per GPU into the root's with an RCCL reduce over xGMI.  The reference is
-// single-GPU and has no counterpart.  librccl is resolved at call time so that single-GPU hosts
-// never load it.
+// single-GPU and has no counterpart.  librccl is resolved on the first multi-context call, so that
+// single-GPU hosts never load it; the library handle and the communicators (one set per device
+// list) are then kept for the life of the contexts.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -24,7 +27,85 @@ typedef const char *(*fn_GetErrorString)(int);
 constexpr int kRcclFloat32 = 7;   // ncclFloat32
 constexpr int kRcclSum = 0;       // ncclSum
 
+// librccl is loaded once per process; communicators are created once per device set and kept until the last
+// context on one of the set's devices is destroyed (ncclCommInitAll costs hundreds of milliseconds on 8 GPUs).
+struct RcclApi {
+    void *lib = nullptr;
+    fn_CommInitAll comm_init_all = nullptr;
+    fn_CommDestroy comm_destroy = nullptr;
+    fn_GroupStart group_start = nullptr;
+    fn_GroupEnd group_end = nullptr;
+    fn_Reduce reduce = nullptr;
+    fn_GetErrorString err_str = nullptr;
+    std::string load_error;
+};
+struct CommSet {
+    std::vector<int> devs;          // in rank order
+    std::vector<rcclComm> comms;
+};
+std::mutex g_mutex;                 // guards everything below
+RcclApi g_api;
+std::vector<CommSet> g_sets;
+std::map<int, int> g_live_contexts; // device -> contexts alive on it
+
+bool load_api()
+{
+    if (g_api.lib) return true;
+    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) { const char *e = dlerror(); g_api.load_error = std::string("cannot load librccl: ") + (e ? e : "?"); return false; }
+    RcclApi a;
+    a.comm_init_all = (fn_CommInitAll)dlsym(lib, "ncclCommInitAll");
+    a.comm_destroy = (fn_CommDestroy)dlsym(lib, "ncclCommDestroy");
+    a.group_start = (fn_GroupStart)dlsym(lib, "ncclGroupStart");
+    a.group_end = (fn_GroupEnd)dlsym(lib, "ncclGroupEnd");
+    a.reduce = (fn_Reduce)dlsym(lib, "ncclReduce");
+    a.err_str = (fn_GetErrorString)dlsym(lib, "ncclGetErrorString");
+    if (!a.comm_init_all || !a.comm_destroy || !a.group_start || !a.group_end || !a.reduce) {
+        g_api.load_error = "librccl lacks a required symbol";
+        dlclose(lib);
+        return false;
+    }
+    a.lib = lib;
+    g_api = a;
+    return true;
+}
+
+void destroy_set(CommSet &cs)
+{
+    for (rcclComm c : cs.comms) if (c) g_api.comm_destroy(c);
+    cs.comms.clear();
+}
+
 }  // namespace
+
+namespace ptx {
+
+void rccl_context_created(int device)
+{
+    std::lock_guard<std::mutex> lock(g_mutex);
+    g_live_contexts[device]++;
+}
+
+// ptx_destroy: when the last context of a device goes, the communicators that span that device go with it
+void rccl_context_destroyed(int device)
+{
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto it = g_live_contexts.find(device);
+    if (it == g_live_contexts.end() || --it->second > 0) return;
+    g_live_contexts.erase(it);
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (size_t i = 0; i < g_sets.size();) {
+        bool spans = false;
+        for (int d : g_sets[i].devs) spans = spans || d == device;
+        if (spans) { destroy_set(g_sets[i]); g_sets.erase(g_sets.begin() + (long)i); }
+        else ++i;
+    }
+    if (have_cur) (void)hipSetDevice(cur);
+}
+
+}  // namespace ptx
 
 extern "C" int ptx_reduce_accumulation(ptx_context **ctxs, int n, int root)
 {
@@ -42,35 +123,41 @@ extern "C" int ptx_reduce_accumulation(ptx_context **ctxs, int n, int root)
     }
     if (n == 1) return ptx_synchronize(rc);
 
-    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) return ptx::ctx_fail(rc, PTX_ERR_HIP, std::string("ptx_reduce_accumulation: cannot load librccl: ") + dlerror());
-    fn_CommInitAll comm_init_all = (fn_CommInitAll)dlsym(lib, "ncclCommInitAll");
-    fn_CommDestroy comm_destroy = (fn_CommDestroy)dlsym(lib, "ncclCommDestroy");
-    fn_GroupStart group_start = (fn_GroupStart)dlsym(lib, "ncclGroupStart");
-    fn_GroupEnd group_end = (fn_GroupEnd)dlsym(lib, "ncclGroupEnd");
-    fn_Reduce reduce = (fn_Reduce)dlsym(lib, "ncclReduce");
-    fn_GetErrorString err_str = (fn_GetErrorString)dlsym(lib, "ncclGetErrorString");
-    if (!comm_init_all || !comm_destroy || !group_start || !group_end || !reduce)
-        return ptx::ctx_fail(rc, PTX_ERR_HIP, "ptx_reduce_accumulation: librccl lacks a required symbol");
-
+    int caller_device = 0;
+    const bool have_caller_device = hipGetDevice(&caller_device) == hipSuccess;
     for (int i = 0; i < n; ++i)
         if (int r = ptx_synchronize(ctxs[i])) return r;
-    std::vector<rcclComm> comms(n, nullptr);
-    int e = comm_init_all(comms.data(), n, devs.data());
-    if (e) return ptx::ctx_fail(rc, PTX_ERR_HIP, std::string("ncclCommInitAll: ") + (err_str ? err_str(e) : "error"));
     int status = PTX_OK;
-    e = group_start();
-    for (int i = 0; i < n && !e; ++i) {
-        (void)hipSetDevice(devs[i]);
-        void *buf = ptx::ctx_albedo(ctxs[i]);
-        e = reduce(buf, buf, np * 4, kRcclFloat32, kRcclSum, root, comms[i], ptx::ctx_stream(ctxs[i]));
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (!load_api()) return ptx::ctx_fail(rc, PTX_ERR_HIP, "ptx_reduce_accumulation: " + g_api.load_error);
+        CommSet *cs = nullptr;
+        for (CommSet &c : g_sets) if (c.devs == devs) cs = &c;
+        if (!cs) {
+            CommSet fresh;
+            fresh.devs = devs;
+            fresh.comms.assign(n, nullptr);
+            int e = g_api.comm_init_all(fresh.comms.data(), n, devs.data());
+            if (e) {
+                destroy_set(fresh);
+                if (have_caller_device) (void)hipSetDevice(caller_device);
+                return ptx::ctx_fail(rc, PTX_ERR_HIP, std::string("ncclCommInitAll: ") + (g_api.err_str ? g_api.err_str(e) : "error"));
+            }
+            g_sets.push_back(fresh);
+            cs = &g_sets.back();
+        }
+        int e = g_api.group_start();
+        for (int i = 0; i < n && !e; ++i) {
+            (void)hipSetDevice(devs[i]);
+            void *buf = ptx::ctx_albedo(ctxs[i]);
+            e = g_api.reduce(buf, buf, np * 4, kRcclFloat32, kRcclSum, root, cs->comms[i], ptx::ctx_stream(ctxs[i]));
+        }
+        int e2 = g_api.group_end();
+        if (e || e2) status = ptx::ctx_fail(rc, PTX_ERR_HIP, std::string("ncclReduce: ") + (g_api.err_str ? g_api.err_str(e ? e : e2) : "error"));
     }
-    int e2 = group_end();
-    if (e || e2) status = ptx::ctx_fail(rc, PTX_ERR_HIP, std::string("ncclReduce: ") + (err_str ? err_str(e ? e : e2) : "error"));
     for (int i = 0; i < n; ++i) (void)ptx_synchronize(ctxs[i]);
-    for (int i = 0; i < n; ++i) if (comms[i]) comm_destroy(comms[i]);
-    if (status) return status;
     // mean of the per-GPU means (each GPU rendered the same number of samples); alpha back to 1
-    return ptx_import_albedo_device(rc, ptx::ctx_albedo(rc), np * 16, 1.0f / (float)n);
+    if (!status) status = ptx_import_albedo_device(rc, ptx::ctx_albedo(rc), np * 16, 1.0f / (float)n);
+    if (have_caller_device) (void)hipSetDevice(caller_device);
+    return status;
 }

@@ -24,6 +24,7 @@ bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &
     if (!f) { err = "cannot open " + path; return false; }
     f.seekg(0, std::ios::end);
     std::streamoff n = f.tellg();
+    if (n < 0) { err = "cannot size " + path; return false; }      // not seekable (a directory, a pipe)
     f.seekg(0);
     out.resize((size_t)n);
     if (n && !f.read((char *)out.data(), n)) { err = "cannot read " + path; return false; }
@@ -126,12 +127,15 @@ struct HuffTable {
     uint8_t vals[256] = {0};
     int mincode[17], maxcode[18], valptr[17];
     uint16_t fast[512];      // (symbol << 8) | length for codes of <= 9 bits, 0 = slow path
-    void build()
+    // false: the code lengths over-subscribe the code space (more codes of some length than a prefix code has
+    // room for) -- such a table would index past `fast` and is rejected
+    bool build()
     {
         int code = 0, k = 0;
         for (int i = 0; i < 512; ++i) fast[i] = 0;
         for (int l = 1; l <= 16; ++l) {
             valptr[l] = k; mincode[l] = code;
+            if (code + (int)bits[l] > (1 << l)) return false;      // Kraft inequality violated
             for (int i = 0; i < bits[l]; ++i, ++k, ++code) {
                 if (l <= 9) {
                     int first = code << (9 - l), n = 1 << (9 - l);
@@ -142,6 +146,7 @@ struct HuffTable {
             code <<= 1;
         }
         maxcode[17] = 0x7FFFFFFF;
+        return true;
     }
 };
 
@@ -316,7 +321,8 @@ bool decode_jpeg(const std::vector<uint8_t> &d, Image &img, std::string &err)
                 i += 16;
                 if (total > 256 || i + total > n) { err = "JPEG: bad DHT"; return false; }
                 memcpy(t.vals, &s[i], total); i += total;
-                t.present = true; t.build();
+                if (!t.build()) { t.present = false; err = "JPEG: bad DHT"; return false; }
+                t.present = true;
             }
         } else if (m == 0xC0 || m == 0xC1) {
             if (n < 6) { err = "JPEG: bad SOF"; return false; }
@@ -337,6 +343,7 @@ bool decode_jpeg(const std::vector<uint8_t> &d, Image &img, std::string &err)
             if (n >= 12 && !memcmp(s, "Adobe", 5)) adobe_transform = s[11];
         } else if (m == 0xDA) {
             if (!have_sof || W == 0 || H == 0) { err = "JPEG: SOS before SOF"; return false; }
+            if (n < 1) { err = "JPEG: bad SOS"; return false; }
             int ns = s[0];
             if (ns != ncomp || n < 1 + 2 * (size_t)ns + 3) { err = "JPEG: non-interleaved multi-scan files are not supported"; return false; }
             for (int k = 0; k < ns; ++k) {

@@ -52,6 +52,13 @@ int main(int argc, char **argv)
     std::mt19937 rng(12345);
     int decoded = 0, rejected = 0;
     for (int i = 2; i < argc; ++i) {
+        if (!strncmp(argv[i], "bad:", 4)) {                // a crafted malformed file: must be rejected cleanly
+            std::vector<uint8_t> b = slurp(argv[i] + 4);
+            if (b.empty()) { fprintf(stderr, "cannot read %s\n", argv[i] + 4); return 2; }
+            if (decode_bytes(b, tmp)) { fprintf(stderr, "%s decodes, it must not\n", argv[i] + 4); return 3; }
+            ++rejected;
+            continue;
+        }
         std::vector<uint8_t> d = slurp(argv[i]);
         if (d.empty()) { fprintf(stderr, "cannot read %s\n", argv[i]); return 2; }
         if (!decode_bytes(d, tmp)) { fprintf(stderr, "%s does not decode\n", argv[i]); return 3; }

@@ -29,11 +29,13 @@ def test_c2_spheres_720p_bit_exact(oracle, gpu_ctx_factory, standins_ready):
     upload(ctx, ing, oracle)
     sc = oracle.scene_from_ingest(ing)
     cam = oracle.camera_matrices([7.0, 2.0, 0.0], oracle.yaw_quat(90), np.deg2rad(np.float32(70)), 1280 / 720, 0.1, 1000.0)
-    want = sc.render(cam, 1280, 720, 2, SEED)
-    got = gpu_render(ctx, oracle, cam, 1280, 720, 2)
-    assert_images_bit_equal(got, want, "spheres 1280x720x2")
+    spp = 24                                     # config: 256 spp; 24 is what the oracle does in a few seconds on the box
+    want = sc.render(cam, 1280, 720, spp, SEED)
+    got = gpu_render(ctx, oracle, cam, 1280, 720, spp)
+    assert_images_bit_equal(got, want, "spheres 1280x720x%d" % spp)
     st = ctx.stats()
     assert st["bvh_triangles"] == 12 + 3 * 491520
+    assert st["rays"] == want["stats"]["rays"] and st["hits"] == want["stats"]["hits"]
 
 
 def test_c3_sponza_1080p_bit_exact_and_c5_4k_primary_ids(oracle, gpu_ctx_factory, standins_ready):
@@ -290,3 +292,57 @@ def test_fused_tail_launch_equals_bounce_by_bounce(oracle, monkeypatch):
             outs[tail] = got
             ctx.close()
         assert_images_bit_equal(outs[16384], outs[0], "tail vs bounce by bounce")
+
+
+def test_reduce_accumulation_two_devices(oracle):
+    """ptx_reduce_accumulation over two contexts on two GPUs (RCCL, cached communicator): GPU g renders sample
+    slice g; the reduced image on the root must equal one context rendering all the samples up to fp32 summation
+    order.  Called twice (the second call reuses the communicator) and the caller's device is left as it was.
+    Skipped on a one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from helpers import rel_mse
+    from path_tracer_amd import capi
+    ing = cornell()
+    cam = oracle.camera_matrices([0, 1.0, 3.9], oracle.yaw_quat(0), np.deg2rad(np.float32(40)), 1.0, 0.1, 1000.0)
+    ctxs = [capi.Context(d) for d in (0, 1)]
+    for c in ctxs:
+        upload(c, ing, oracle)
+    torch.cuda.set_device(0)
+    single = gpu_render(ctxs[0], oracle, cam, 128, 128, 32, params=capi.default_params(max_depth=8))["albedo"]
+    for round_ in range(2):
+        parts = [gpu_render(c, oracle, cam, 128, 128, 16, params=capi.default_params(max_depth=8, rng_sample_offset=16 * g))["albedo"]
+                 for g, c in enumerate(ctxs)]
+        capi.reduce_accumulation(ctxs, root=0)
+        assert torch.cuda.current_device() == 0
+        got = ctxs[0].read_image(capi.IMAGE_ALBEDO)
+        host_mean = ((parts[0].astype(np.float64) + parts[1].astype(np.float64)) / 2.0).astype(np.float32)
+        assert np.max(np.abs(got[..., :3] - host_mean[..., :3])) <= 2e-7, round_
+        assert np.all(got[..., 3] == 1.0)
+        assert rel_mse(got, single) < 1e-9
+    for c in ctxs:
+        c.close()
+
+
+def test_bench_two_rank_rehearsal_reduce_leg():
+    """bench.py's N > 1 path with the real renderer: `python bench.py --gpus 2` as typed (the script launches its own
+    ranks), both ranks on this box's one GPU, the accumulation reduce host-staged over gloo (RCCL refuses two ranks on
+    one device).  Exercises export -> reduce -> import and checks the combined image against one context rendering
+    every rank's samples."""
+    import json
+    import subprocess
+    import sys
+    from helpers import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-gloo", "--workload", "cornell_512",
+                        "--steps", "2", "--warmup", "1", "--spp-per-step", "2", "--max-depth", "8", "--cpu-baseline-spp", "0",
+                        "--verify-reduce"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak"
+    assert d["reduce_check"]["samples_per_rank"] == 4 and d["reduce_check"]["ranks"] == 2    # 2 dirty frames, then 4 accumulated
+    assert d["reduce_check"]["rel_mse_vs_single_context"] < 1e-9, d["reduce_check"]
+    assert d["value"] > 0 and d["steps"] == 2

@@ -42,13 +42,20 @@ def test_render_batch_equals_repeated_render(oracle, cornell_pair):
     assert_images_bit_equal(a, b, "batch vs 5x render")
 
 
-def test_cornell_512_depth8_bit_exact(oracle, cornell_pair):
+def test_c1_cornell_512_64spp_depth8_bit_exact(oracle, cornell_pair):
+    """BASELINE.json config 1 at its real size: 512 x 512, 64 spp, max depth 8, fixed seed (16.8 M pixel-samples;
+    the oracle takes a few seconds on the box's host cores)."""
     sc, ctx = cornell_pair
     cam = cornell_cam(oracle)
     from path_tracer_amd import capi
-    want = sc.render(cam, 512, 512, 2, SEED, params=oracle.default_params(max_depth=8))
-    got = gpu_render(ctx, oracle, cam, 512, 512, 2, params=capi.default_params(max_depth=8))
-    assert_images_bit_equal(got, want, "cornell 512x512x2")
+    want = sc.render(cam, 512, 512, 64, SEED, params=oracle.default_params(max_depth=8))
+    ctx.synchronize()
+    ctx.reset_stats()
+    got = gpu_render(ctx, oracle, cam, 512, 512, 64, params=capi.default_params(max_depth=8))
+    assert_images_bit_equal(got, want, "cornell 512x512x64")
+    st = ctx.stats()
+    assert st["samples"] == 512 * 512 * 64 == want["stats"]["samples"]
+    assert st["rays"] == want["stats"]["rays"] and st["hits"] == want["stats"]["hits"]
 
 
 def test_lion_boulder_textured_bit_exact(oracle, gpu_ctx_factory):
@@ -63,6 +70,28 @@ def test_lion_boulder_textured_bit_exact(oracle, gpu_ctx_factory):
     assert_images_bit_equal(got, want, "lion+boulder 320x180x4")
     assert want["stats"]["textured_hits"] > 0
     assert rel_mse(got["albedo"], want["albedo"]) == 0.0
+
+
+def test_c4_lion_boulder_1080p_both_cameras_bit_exact(oracle, gpu_ctx_factory):
+    """BASELINE.json config 4 at its real size: the scanned lion head (x = +2) and boulder (x = -2) placed as
+    render_window.rs:412-426 does, 1920 x 1080, from both SURVEY.md 8d cameras -- the app's default view
+    (render_window.rs:436) and the close-up that fills the frame with the lion (BVH depth / divergence stress).
+    ids, normal, depth and RGBA32F accumulation bitwise against the oracle; ray / hit counts equal."""
+    ing = lion_boulder()
+    ctx = gpu_ctx_factory()
+    upload(ctx, ing, oracle)
+    sc = oracle.scene_from_ingest(ing)
+    for pos, spp in (([-1.5, 1.0, 5.0], 4), ([2.0, 0.25, 0.6], 4)):
+        cam = oracle.camera_matrices(pos, oracle.yaw_quat(0), np.deg2rad(np.float32(70)), 1920 / 1080, 0.1, 1000.0)
+        want = sc.render(cam, 1920, 1080, spp, SEED)
+        ctx.synchronize()
+        ctx.reset_stats()
+        got = gpu_render(ctx, oracle, cam, 1920, 1080, spp)
+        assert_images_bit_equal(got, want, "lion+boulder 1920x1080x%d from %s" % (spp, pos))
+        st = ctx.stats()
+        assert st["rays"] == want["stats"]["rays"] and st["hits"] == want["stats"]["hits"]
+        assert want["stats"]["textured_hits"] == want["stats"]["hits"] > 0
+    assert ctx.stats()["bvh_triangles"] == 47214 + 66122
 
 
 def test_stress_scene_ties_queue_overflow_many_textures(oracle, gpu_ctx_factory):

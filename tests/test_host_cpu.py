@@ -285,6 +285,17 @@ def test_native_host_code_under_asan_ubsan(tmp_path):
     pngs = sorted((os.path.getsize(os.path.join(sponza, f)), f) for f in os.listdir(sponza) if f.endswith(".png"))
     jpgs = sorted((os.path.getsize(os.path.join(sponza, f)), f) for f in os.listdir(sponza) if f.endswith(".jpg"))
     imgs = [os.path.join(sponza, pngs[0][1]), os.path.join(sponza, jpgs[0][1])]
+    # crafted files: a DHT whose code lengths over-subscribe the code space (three 1-bit codes: such a table indexed
+    # past the decoder's 512-entry fast table), an SOS segment with an empty payload, and a directory as "file"
+    jpg = open(imgs[1], "rb").read()
+    dht = jpg.index(b"\xff\xc4")
+    bad_dht = bytearray(jpg)
+    bad_dht[dht + 5] = 3                                   # marker 2 + length 2 + Tc/Th 1 -> bits[1]
+    sos = jpg.index(b"\xff\xda")
+    bad_sos = jpg[:sos] + b"\xff\xda\x00\x02" + jpg[sos + 4:]
+    for name, data in (("bad_dht.jpg", bytes(bad_dht)), ("bad_sos.jpg", bad_sos)):
+        (tmp_path / name).write_bytes(data)
+        imgs.append("bad:" + str(tmp_path / name))
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:verify_asan_link_order=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe, str(tmp_path / "img.tmp")] + imgs, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr

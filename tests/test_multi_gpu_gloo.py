@@ -112,3 +112,25 @@ def test_progressive_preview_two_ranks(tmp_path, oracle):
         np.testing.assert_array_equal(got["p%d" % (world * m)], want)
     whole = sc.render(cam, W, H, TOTAL_SPP, SEED, threads=2)["albedo"]
     assert np.abs(got["final"] - whole).max() < 2e-6
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` as the driver types it (no WORLD_SIZE in the environment): the parent must start
+    torch.distributed.run as a child process, relay its JSON line and its exit code.  --launch-check with
+    --rehearse-gloo brings the ranks up over gloo and touches no GPU, so the launcher path runs here."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check", "--rehearse-gloo"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d == {"launch_check": True, "n_gpus": 2, "rccl_ranks": 2, "backend": "gloo"}
+    # a rank count that does not match --gpus is an error, not a silent single-GPU run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check", "--rehearse-gloo"],
+                       env=env2, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
