@@ -220,6 +220,18 @@ int ptx_render(ptx_context *ctx, const ptx_uniforms *uniforms, const ptx_camera 
 int ptx_render_batch(ptx_context *ctx, const ptx_uniforms *uniforms, const ptx_camera *camera,
                      const ptx_render_params *params, uint32_t n_samples);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory while rendering (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): one frame exactly like ptx_render -- same
+ * images, bit for bit -- whose wavefront state (ray queues, hit records, per-path results, queue counters) lives in
+ * a file-scope device array of the library instead of buffers allocated on demand.  The call makes no hipMalloc /
+ * hipFree / stream or event creation and no host allocation.  Limits: width x height <= 262 144 pixels (512 x 512),
+ * PTX_INTEGRATOR_REFERENCE only; beyond that it returns PTX_ERR_CAPACITY / PTX_ERR_INVALID with a message.  Every GPU
+ * the library runs on holds its copy of the array (39.98 MB) until the process ends.  All contexts of one GPU share
+ * that GPU's array: calls that overlap on one GPU (two contexts, two threads) race -- serialise them.  Ordered with
+ * the context's other render calls; asynchronous on the context's main stream. */
+int ptx_render_static(ptx_context *ctx, const ptx_uniforms *uniforms, const ptx_camera *camera,
+                      const ptx_render_params *params);
+
 /* Image readback (renderer.rs:668-742).  Synchronises the stream.  Row 0 = top of the view.
  * bytes must equal width*height*{16,16,4,8}. */
 int ptx_read_image(ptx_context *ctx, int kind, void *dst, uint64_t bytes);

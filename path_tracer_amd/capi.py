@@ -77,7 +77,7 @@ EXPORTS = [
     "ptx_set_instances", "ptx_resize", "ptx_render", "ptx_render_batch", "ptx_read_image", "ptx_write_albedo",
     "ptx_export_albedo_device", "ptx_import_albedo_device", "ptx_reduce_accumulation", "ptx_synchronize",
     "ptx_set_profiling", "ptx_get_stats", "ptx_reset_stats", "ptx_last_error",
-    "ptx_set_material_ext", "ptx_set_scene_options", "ptx_update_instances",
+    "ptx_set_material_ext", "ptx_set_scene_options", "ptx_update_instances", "ptx_render_static",
 ]
 
 _lib = None
@@ -116,6 +116,7 @@ def load():
     L.ptx_resize.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.ptx_render.argtypes = [vp, C.POINTER(Uniforms), C.POINTER(Camera), C.POINTER(RenderParams)]
     L.ptx_render_batch.argtypes = [vp, C.POINTER(Uniforms), C.POINTER(Camera), C.POINTER(RenderParams), C.c_uint32]
+    L.ptx_render_static.argtypes = [vp, C.POINTER(Uniforms), C.POINTER(Camera), C.POINTER(RenderParams)]
     L.ptx_read_image.argtypes = [vp, C.c_int, vp, C.c_uint64]
     L.ptx_write_albedo.argtypes = [vp, vp, C.c_uint64]
     L.ptx_export_albedo_device.argtypes = [vp, vp, C.c_uint64, C.c_float]
@@ -229,6 +230,11 @@ class Context:
     def render(self, uniforms, camera, params=None):
         self._check(self._L.ptx_render(self.handle, C.byref(uniforms), C.byref(camera),
                                        C.byref(params) if params is not None else None))
+
+    def render_static(self, uniforms, camera, params=None):
+        """ptx_render_static: one frame with the wavefront state in the library's file-scope device array (no allocation)."""
+        self._check(self._L.ptx_render_static(self.handle, C.byref(uniforms), C.byref(camera),
+                                              C.byref(params) if params is not None else None))
 
     def render_batch(self, uniforms, camera, n_samples, params=None):
         self._check(self._L.ptx_render_batch(self.handle, C.byref(uniforms), C.byref(camera),

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -51,6 +52,40 @@ struct PathSet {
     uint32_t counts_paths = 0, counts_bounces = 0;
     bool counts_lit = false;
 };
+
+// ---- ptx_render_static: the wavefront state of one frame in memory that is never allocated at run time.
+// The two ray queues, the hit records, the per-path results and the chunk counters of a frame of up to
+// kStaticMaxPaths pixels live in ONE file-scope device array.  Every GPU the library runs on holds its own copy
+// (39.98 MB) from module load until the process ends.  In host code the array's name is only a stand-in for the
+// symbol: its device address is looked up once per device (static_scratch_for, called from ptx_create with that
+// device current) and only that address is ever passed to a kernel.
+constexpr uint64_t kStaticMaxPaths = 512ull * 512ull;
+constexpr uint64_t kStaticCounterBytes = (kNumCounters * sizeof(uint32_t) + 255ull) & ~255ull;
+constexpr uint64_t kStaticRayOff = kStaticCounterBytes;
+constexpr uint64_t kStaticHitOff = kStaticRayOff + 2ull * kStaticMaxPaths * kRayBytes;
+constexpr uint64_t kStaticResultOff = kStaticHitOff + kStaticMaxPaths * sizeof(HitOut);
+constexpr uint64_t kStaticBytes = kStaticResultOff + kStaticMaxPaths * sizeof(float4);
+static_assert(kStaticRayOff % 256 == 0 && kStaticHitOff % 256 == 0 && kStaticResultOff % 256 == 0, "sub-buffers stay 256-byte aligned");
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void *g_scratch_ptr[kMaxDevices] = {};      // device address of `scratch` on each device, looked up on first use
+
+// `device` must be the current device.  Returns NULL (and the HIP error in `err`) if the symbol cannot be resolved.
+void *static_scratch_for(int device, hipError_t &err)
+{
+    err = hipSuccess;
+    if (device < 0 || device >= kMaxDevices) { err = hipErrorInvalidDevice; return nullptr; }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        err = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+        if (err != hipSuccess || !p) { if (err == hipSuccess) err = hipErrorInvalidSymbol; return nullptr; }
+        g_scratch_ptr[device] = p;
+    }
+    return g_scratch_ptr[device];
+}
 
 }  // namespace
 
@@ -114,6 +149,8 @@ struct ptx_context {
     uint32_t tail_rays = 65536;             // PTX_TAIL_RAYS: expected queue length at or below which the tail takes over; 0: never
     hipEvent_t last_resolved = nullptr;     // = sets[k].resolved of the most recent chunk: the next resolve waits for it
     hipEvent_t last_first_shade = nullptr;  // = sets[k].first_shade of the most recent chunk: the next bounce-0 shading waits for it
+    hipEvent_t static_done = nullptr;       // recorded on `stream` behind each ptx_render_static frame
+    unsigned char *static_scratch = nullptr; // this device's copy of the file-scope scratch array (never freed)
     bool counted = false;                   // rccl_context_created has been called for this context
     uint64_t *d_totals = nullptr;           // rays, hits, samples, nodes fetched, triangles tested
 
@@ -373,6 +410,12 @@ int ptx_create_with_limits(int device_ordinal, const ptx_limits *limits, ptx_con
     } while (0)
     CREATE_TRY(hipSetDevice(device_ordinal));
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&c->static_done, hipEventDisableTiming));
+    {
+        hipError_t se = hipSuccess;
+        c->static_scratch = (unsigned char *)static_scratch_for(device_ordinal, se);
+        CREATE_TRY(se);
+    }
     if (const char *ts = getenv("PTX_TAIL_SHIFT")) { long v = strtol(ts, nullptr, 10); if (v >= 0 && v <= 31) c->tail_shift = (uint32_t)v; }
     if (const char *tr = getenv("PTX_TAIL_RAYS")) { long v = strtol(tr, nullptr, 10); if (v >= 0) c->tail_rays = (uint32_t)std::min<long>(v, 1 << 24); }
     if (const char *fi = getenv("PTX_FRAMES_IN_FLIGHT")) { long v = strtol(fi, nullptr, 10); if (v >= 1 && v <= kMaxSets) c->n_sets = (int)v; }
@@ -414,6 +457,7 @@ int ptx_destroy(ptx_context *c)
         if (ps.stream) (void)hipStreamDestroy(ps.stream);
     }
     dfree(c->d_totals);
+    if (c->static_done) (void)hipEventDestroy(c->static_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->counted) rccl_context_destroyed(c->device);
     delete c;
@@ -1023,6 +1067,74 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
 int ptx_render(ptx_context *c, const ptx_uniforms *u, const ptx_camera *cam, const ptx_render_params *p)
 {
     return ptx_render_batch(c, u, cam, p, 1);
+}
+
+// One frame (1 sample per pixel) like ptx_render, with the wavefront state in the file-scope scratch array of the
+// context's device: no hipMalloc / hipFree, no event or stream creation, no host allocation.  Runs on the context's
+// main stream, bounce by bounce (no frames in flight, no fused tail, no profiling events), ordered after every
+// ptx_render / ptx_render_batch chunk issued before it and before every one issued after it.
+int ptx_render_static(ptx_context *c, const ptx_uniforms *u, const ptx_camera *cam, const ptx_render_params *pp)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (!u || !cam) return fail(c, PTX_ERR_INVALID, "ptx_render_static: NULL argument");
+    if (!c->scene_ready) return fail(c, PTX_ERR_STATE, "ptx_render_static: ptx_set_instances has not been called");
+    if (!c->width) return fail(c, PTX_ERR_STATE, "ptx_render_static: ptx_resize has not been called");
+    ptx_render_params p;
+    if (pp) p = *pp; else ptx_default_params(&p);
+    if (p.max_depth > kMaxDepthLimit) return fail(c, PTX_ERR_INVALID, "ptx_render_static: max_depth above 64");
+    if (p.integrator != PTX_INTEGRATOR_REFERENCE)
+        return fail(c, PTX_ERR_INVALID, "ptx_render_static: only PTX_INTEGRATOR_REFERENCE (the lit integrator's occlusion queue is not part of the static scratch)");
+    const uint64_t npix = (uint64_t)c->width * c->height;
+    if (npix > kStaticMaxPaths)
+        return fail(c, PTX_ERR_CAPACITY, "ptx_render_static: image has more than 262144 pixels (512 x 512), the size the static scratch holds; use ptx_render");
+    if (!c->static_scratch) return fail(c, PTX_ERR_STATE, "ptx_render_static: the static scratch of this device was not resolved");
+    if (int r = bind(c)) return r;
+
+    unsigned char *base = c->static_scratch;
+    uint32_t *counters = reinterpret_cast<uint32_t *>(base);
+    void *rays[2] = {base + kStaticRayOff, base + kStaticRayOff + kStaticMaxPaths * kRayBytes};
+    HitOut *hits = reinterpret_cast<HitOut *>(base + kStaticHitOff);
+    float4 *results = reinterpret_cast<float4 *>(base + kStaticResultOff);
+    const uint32_t n_paths = (uint32_t)npix;
+
+    SceneDev sc;
+    sc.lit_materials = c->d_lit_materials; sc.lights = c->d_lights; sc.light_cdf = c->d_light_cdf; sc.n_lights = c->n_lights;
+    sc.nodes = c->d_nodes; sc.n_nodes = c->n_nodes; sc.tris = c->d_tris; sc.shade = c->d_shade;
+    sc.textures = c->d_textures; sc.n_textures = c->n_dev_textures; sc.srgb_lut = c->d_lut;
+    ImagesDev img; img.albedo = c->d_albedo; img.normal = c->d_normal; img.depth = c->d_depth; img.ids = c->d_ids;
+    FrameDev f;
+    f.cam = *cam;
+    {
+        const float *m = cam->view_inverse;     // rgen.glsl:30, as ptx_render_batch
+        for (int a = 0; a < 3; ++a) f.cam_origin[a] = ((m[a] * 0.0f + m[4 + a] * 0.0f) + m[8 + a] * 0.0f) + m[12 + a] * 1.0f;
+    }
+    f.width = c->width; f.height = c->height; f.n_pixels = n_paths;
+    f.seed = u->seed; f.rng_offset = p.rng_sample_offset;
+    f.max_depth = p.max_depth; f.t_min = p.t_min; f.t_max = p.t_max; f.normal_eps = p.normal_eps;
+    f.z_near = u->z_near; f.z_far = u->z_far;
+    f.tex_times_factor = (c->built_options & PTX_SCENE_TEXTURE_TIMES_FACTOR) ? 1u : 0u;
+    f.mean_base = u->accumulated_count;
+    f.ids_sample = 0u;
+    const uint32_t bounces = std::max(1u, p.max_depth);
+
+    hipStream_t st = c->stream;
+    // behind the chunks already in flight on the path sets: their G-buffer writes and their resolves
+    if (c->last_first_shade && c->last_first_shade != c->static_done) HIP_TRY(c, hipStreamWaitEvent(st, c->last_first_shade, 0));
+    if (c->last_resolved && c->last_resolved != c->static_done) HIP_TRY(c, hipStreamWaitEvent(st, c->last_resolved, 0));
+    // k_raygen's first block clears every counter and fetch head the frame uses: nothing is kept from the last call
+    launch_raygen(st, f, n_paths, make_ray_queue(rays[0], kStaticMaxPaths), counters);
+    for (uint32_t b = 0; b < bounces; ++b) {
+        RayQueue rin = make_ray_queue(rays[b & 1], kStaticMaxPaths), rout = make_ray_queue(rays[(b & 1) ^ 1], kStaticMaxPaths);
+        launch_extend(st, sc, f, rin, counters + b, counters + fetch_heads(b, 0), n_paths, c->extend_waves, hits, nullptr, false, b == 0);
+        launch_shade(st, sc, f, img, b, rin, hits, counters, n_paths, rout, results);
+    }
+    launch_resolve(st, f, img, results, 1);
+    launch_accumulate_stats(st, counters, bounces, (uint64_t)n_paths, c->d_totals);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->static_done, st));
+    c->last_resolved = c->static_done;
+    c->last_first_shade = c->static_done;
+    return PTX_OK;
 }
 
 int ptx_read_image(ptx_context *c, int kind, void *dst, uint64_t bytes)
