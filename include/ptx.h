@@ -159,6 +159,9 @@ typedef struct {
     uint64_t bvh_builds, bvh_refits;       /* acceleration-structure builds / refits since ptx_create */
     uint64_t bvh_device_refits;            /* of the refits, those done entirely on the GPU */
     uint64_t tail_launches;                /* chunks whose last bounces ran as one fused launch (since ptx_reset_stats) */
+    uint64_t extend_phase_cycles[8];       /* level 2: shader cycles of wave lifetime per phase of the traversal kernel, summed over waves: ray
+                                              fetch, node-load wait, node test + pick, triangle-queue append, triangle fetch wait, triangle
+                                              test, hand-back of the hits, retire + loop control */
 } ptx_stats;
 
 typedef struct ptx_context ptx_context;

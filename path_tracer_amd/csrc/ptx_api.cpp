@@ -677,6 +677,8 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
             return fail(c, PTX_ERR_INVALID, "ptx_set_instances: material refers to a texture that was never added");
         n_tris += g.n_indices / 3;
     }
+    if (n_tris > kMaxSceneTriangles)
+        return fail(c, PTX_ERR_CAPACITY, "ptx_set_instances: more than 67 108 863 instanced triangles (the traversal kernel's 26-bit triangle index)");
 
     // Same entities, new transforms (the reference rebuilds its TLAS every frame, renderer.rs:961, and wants not
     // to: todo.md:3): keep the tree and refit its boxes, unless the moved scene has made it too loose.
@@ -1234,6 +1236,7 @@ int ptx_get_stats(ptx_context *c, ptx_stats *s)
     s->bvh_bytes = (uint64_t)c->n_nodes * sizeof(Bvh8Node) + c->n_tris * (sizeof(TriRec) + sizeof(ShadeRec));
     s->bvh_depth = c->bvh_depth;
     s->shadow_rays = t[11]; s->lights = c->n_lights;
+    for (int i = 0; i < 8; ++i) s->extend_phase_cycles[i] = t[12 + i];
     s->bvh_builds = c->n_builds; s->bvh_refits = c->n_refits; s->bvh_device_refits = c->n_device_refits;
     s->tail_launches = c->n_tail_launches;
     return PTX_OK;

@@ -120,6 +120,11 @@ constexpr uint32_t kHeadsPerLaunch = kFetchHeads * kHeadStride;
 constexpr uint32_t kNumCounters = kHeadBase + kMaxDepthLimit * 2 * kHeadsPerLaunch;
 inline constexpr uint32_t fetch_heads(uint32_t bounce, uint32_t kind) { return kHeadBase + (bounce * 2u + kind) * kHeadsPerLaunch; }
 
+// Leaf-ordered triangle indices fit 26 bits (the traversal kernel packs an index with a 6-bit lane number);
+// ptx_set_instances refuses scenes with more triangles.
+constexpr uint32_t kTriIndexBits = 26;
+constexpr uint64_t kMaxSceneTriangles = (1ull << kTriIndexBits) - 1ull;
+
 // traversal stack: entries held in LDS per lane, remainder in private memory
 #ifndef PTX_LDS_STACK
 #define PTX_LDS_STACK 8
@@ -151,7 +156,7 @@ void launch_shadow_resolve(hipStream_t s, uint32_t depth, RayQueue shadow, const
 void launch_resolve(hipStream_t s, const FrameDev &f, const ImagesDev &img, const float4 *results, uint32_t n_samples);
 void launch_accumulate_stats(hipStream_t s, const uint32_t *counters, uint32_t max_depth, uint64_t n_samples,
                              uint64_t *totals);
-constexpr int kNumTotals = 12;   // rays, hits, samples, nodes, tris, 6 x wave_sched, shadow rays
+constexpr int kNumTotals = 20;   // rays, hits, samples, nodes, tris, 6 x wave_sched, shadow rays, 8 x traversal phase cycles
 void launch_scale_copy(hipStream_t s, const float4 *src, float4 *dst, uint64_t n, float scale);
 
 // ---- device refit (ptx_refit.hip): instance motion without a host round trip

@@ -126,6 +126,7 @@ struct ExtendSched {
 #endif
 
 constexpr uint32_t kTriQueue = 128;   // entries, power of two
+static_assert(kTriIndexBits == 26, "a queue entry is 26 bits of triangle index + 6 bits of owner lane");
 
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -168,9 +169,9 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
            ExtendSched sched)
 {
     __shared__ uint2 s_stack[kLdsStack * kExtendBlock];
-    __shared__ uint32_t s_qtri[kTriQueue];
-    __shared__ uint8_t s_qown[kTriQueue];
+    __shared__ uint32_t s_qtri[kTriQueue];      // pending (triangle, owner lane) pairs: triangle index | owner << kTriIndexBits
     __shared__ uint8_t s_claim[kExtendBlock];
+    __shared__ float s_dir[3][kExtendBlock];      // direction of each lane's ray: the triangle block reads its pair owner's
     const uint32_t n = *count;
     const uint32_t lane_id = threadIdx.x;
     uint2 ovf_store[kOvfStack];
@@ -183,11 +184,24 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
     tr.o = mk3(0.0f, 0.0f, 0.0f); tr.hit.t = 0.0f;
     tr.t_min = t_min; tr.t_max = t_max;     // wave-uniform: keeps them out of the VGPRs
     bool active = false;
+    bool unwritten = false;             // this lane's finished ray has not been stored yet: all such lanes store together at the next refill
     uint32_t ray = 0;
     uint32_t next_ni = 0xFFFFFFFFu;
     uint32_t q_head = 0, q_tail = 0;    // wave-uniform, monotone (mod 2^32)
     uint32_t my_tail = 0;               // q_tail just after this lane's latest pair
     unsigned long long tot_nodes = 0, tot_tris = 0;
+    // instrumented build only: wave lifetime per phase (s_memtime deltas; a stamp first drains the wave's memory
+    // counters, so "wait" phases hold exactly the time until the data was there)
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ph_t = kStats ? __builtin_amdgcn_s_memtime() : 0ull;
+#define PTX_PHASE(i)                                                                     \
+    do {                                                                                 \
+        if (kStats) {                                                                    \
+            __builtin_amdgcn_s_waitcnt(0);                                               \
+            unsigned long long now_ = __builtin_amdgcn_s_memtime();                      \
+            ph[i] += now_ - ph_t; ph_t = now_;                                           \
+        }                                                                                \
+    } while (0)
     unsigned long long w_iters = 0, w_node_blocks = 0, w_node_lanes = 0, w_tri_blocks = 0, w_tri_lanes = 0, w_refills = 0;
     uint32_t chunk_next = 0, chunk_end = 0;
     // Rays are handed out in chunks, one atomic each.  A single word takes ~88 M atomics/s, so a long queue of cheap
@@ -215,6 +229,13 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
         unsigned long long idle = __ballot(!active);
         if (!exhausted && __popcll(idle) >= sched.refill) {
             if (kStats) w_refills++;
+            // The results of the rays that finished since the last refill leave in ONE store here.  A store per
+            // iteration (a few lanes retire in almost every one) sat in front of every node fetch: vmcnt counts
+            // loads and stores together and in order, so each fetch also waited for the store before it.
+            if (unwritten) {
+                *reinterpret_cast<float2 *>(hits + ray) = make_float2(tr.hit.t, __uint_as_float(tr.hit.tri));
+                unwritten = false;
+            }
             for (int pass = 0; pass < 2 && idle != 0ull; ++pass) {
                 if (chunk_next == chunk_end) {
                     bool got = false;
@@ -241,6 +262,7 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                 uint32_t avail = chunk_end - chunk_next;
                 if (!active && rank < avail) {
                     uint32_t i = chunk_next + rank;
+                    const float4 r1 = rays.dir[i];
                     const float4 r3 = rays.inv[i];
                     const float4 r0 = sched.primary ? make_float4(sched.cam_o[0], sched.cam_o[1], sched.cam_o[2], __uint_as_float(i)) : rays.org[i];
                     bool go = tr.init_prepared(sc.n_nodes, mk3(r0.x, r0.y, r0.z), r3.x, r3.y, r3.z, __float_as_uint(r3.w), t_min, t_max, st);
@@ -248,12 +270,14 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                     ray = i;
                     my_tail = q_head;
                     active = true;
+                    s_dir[0][lane_id] = r1.x; s_dir[1][lane_id] = r1.y; s_dir[2][lane_id] = r1.z;
                 }
                 uint32_t n_idle = (uint32_t)__popcll(idle);
                 chunk_next += (n_idle < avail) ? n_idle : avail;
                 idle = __ballot(!active);
             }
         }
+        PTX_PHASE(0);
         if (__ballot(active) == 0) {
             if (exhausted) break;
             continue;
@@ -265,7 +289,16 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
             const int nb = __popcll(__ballot(want_node));
             if (kStats) { w_iters++; if (nb) { w_node_blocks++; w_node_lanes += nb; } }
             if (nb > 0) {
-                if (want_node) {
+                if (kStats) {
+                    Words80 nw;
+                    if (want_node) nw = load_node(sc.nodes, next_ni);
+                    PTX_PHASE(1);
+                    if (want_node) {
+                        tr.node_eval(nw);
+                        next_ni = tr.next_group(st) ? tr.node_pick(st) : 0xFFFFFFFFu;
+                    }
+                    PTX_PHASE(2);
+                } else if (want_node) {
                     tr.node_eval(load_node(sc.nodes, next_ni));
                     next_ni = tr.next_group(st) ? tr.node_pick(st) : 0xFFFFFFFFu;
                 }
@@ -287,13 +320,13 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                     do {
                         uint32_t ti = tr.tri_pick();
                         uint32_t idx = pos & (kTriQueue - 1u);
-                        s_qtri[idx] = ti;
-                        s_qown[idx] = (uint8_t)lane_id;
+                        s_qtri[idx] = ti | (lane_id << kTriIndexBits);
                         ++pos;
                     } while (tr.tg_mask != 0);
                 }
                 q_tail += total;
             }
+            PTX_PHASE(3);
             // ---- triangle tests, a full wave's worth at a time
             {
                 const uint32_t qn = q_tail - q_head;
@@ -306,24 +339,29 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                     if (kStats) { w_tri_blocks++; w_tri_lanes += nt; }
                     const bool has = lane_id < nt;
                     const uint32_t idx = (q_head + lane_id) & (kTriQueue - 1u);
-                    uint32_t ti = has ? s_qtri[idx] : 0u;
-                    uint32_t own = has ? (uint32_t)s_qown[idx] : lane_id;
-                    // the owner's ray: origin and current closest t from its registers, direction
-                    // from the ray queue (not kept in registers: the node walk only needs 1/d)
+                    const uint32_t entry = has ? s_qtri[idx] : (lane_id << kTriIndexBits);
+                    const uint32_t ti = entry & ((1u << kTriIndexBits) - 1u), own = entry >> kTriIndexBits;
+                    // the owner's ray: origin and current closest t from its registers (ds_bpermute), direction from
+                    // the wave's LDS block (not kept in registers: the node walk only needs 1 / d; re-reading it from
+                    // the ray queue put a cold global load on the block's dependent chain)
                     f3 o = mk3(lane_read_f(tr.o.x, own), lane_read_f(tr.o.y, own), lane_read_f(tr.o.z, own));
                     float ht = lane_read_f(tr.hit.t, own);
-                    uint32_t oray = lane_read_u(ray, own);
                     float t = 0.0f;
                     bool cand = false;
+                    f3 dd = mk3(0.0f, 0.0f, 1.0f);
+                    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
                     if (has) {
-                        const float *dp = reinterpret_cast<const float *>(rays.dir + oray);
-                        f3 dd = mk3(dp[0], dp[1], dp[2]);
+                        dd = mk3(s_dir[0][own], s_dir[1][own], s_dir[2][own]);
                         const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + ti);
-                        float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
+                        r0 = tp[0]; r1 = tp[1]; r2 = tp[2];
+                    }
+                    PTX_PHASE(4);
+                    if (has) {
                         cand = tri_test_t(o, dd, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), mk3(r2.x, r2.y, r2.z),
                                           t_min, t_max, t) && t <= ht;
                         if (kStats) tot_tris++;
                     }
+                    PTX_PHASE(5);
                     q_head += nt;
                     // hand the successful tests to their owners; two pairs of one owner take two rounds
                     while (__ballot(cand) != 0ull) {
@@ -352,23 +390,28 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                         }
                         cand = cand && !won;
                     }
+                    PTX_PHASE(6);
                 }
             }
             // ---- rays whose walk is over and whose pairs have all been tested
             if (active && next_ni == 0xFFFFFFFFu && tr.tg_mask == 0 && (int)(q_head - my_tail) >= 0) {
-                *reinterpret_cast<float2 *>(hits + ray) = make_float2(tr.hit.t, __uint_as_float(tr.hit.tri));
                 if (kStats) tot_nodes += tr.stats.nodes;
                 active = false;
+                unwritten = true;
             }
+            PTX_PHASE(7);
         } while (__popcll(__ballot(active)) > stop_at);
     }
+    if (unwritten) *reinterpret_cast<float2 *>(hits + ray) = make_float2(tr.hit.t, __uint_as_float(tr.hit.tri));
     if (kStats) {
         atomicAdd(&trav_totals[0], tot_nodes);
         atomicAdd(&trav_totals[1], tot_tris);
         if (threadIdx.x == 0) {
             atomicAdd(&trav_totals[2], w_iters); atomicAdd(&trav_totals[3], w_node_blocks); atomicAdd(&trav_totals[4], w_node_lanes);
             atomicAdd(&trav_totals[5], w_tri_blocks); atomicAdd(&trav_totals[6], w_tri_lanes); atomicAdd(&trav_totals[7], w_refills);
+            for (int i = 0; i < 8; ++i) atomicAdd(&trav_totals[9 + i], ph[i]);      // totals[12 + i]: trav_totals = totals + 3
         }
+#undef PTX_PHASE
     }
 }
 
