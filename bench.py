@@ -41,6 +41,11 @@ WORKLOADS = {
                         res=(512, 512), geometry="real"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
+VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md "Peak FP32 (vector)"
+LANE_OPS_NODE, LANE_OPS_TRI = 112.0, 60.0      # algorithmic lane-ops per 8-wide node visit / per watertight triangle test
+PHASE_NAMES = ["ray fetch", "node-load wait", "node test + pick", "queue append", "triangle fetch wait", "triangle test",
+               "hit hand-back", "retire + loop"]
 # per node visit, per triangle test (48 B of vertices + the 12 B ray direction it re-reads), ray fetch, hit record
 NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 80, 60, 32, 8
 
@@ -222,32 +227,44 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel (k_extend, BVH traversal): algorithmic bytes per launch ----
+        # ---- roofline of the dominant kernel (k_extend, BVH traversal) ----
+        # One untimed instrumented step of the same workload (profiling level 2: counting traversal kernel, every chunk
+        # on one stream): nodes fetched / triangles tested per ray, lane occupancy of the wave-level blocks, per-phase
+        # wave cycles, and the shading kernels' own time (in the timed region two chunks overlap on two streams, so a
+        # stage's HIP-event time there includes waiting behind the other chunk's kernels).
         ctx.set_profiling(2)
         ctx.reset_stats()
-        r.record_commands_batch(spp)          # one untimed instrumented step: nodes fetched / triangles tested
+        r.record_commands_batch(spp)
         ist = ctx.stats()
         ctx.set_profiling(0)
         nodes_per_ray = ist["nodes_fetched"] / max(1, ist["rays"])
         tris_per_ray = ist["tris_tested"] / max(1, ist["rays"])
-        bytes_per_ray = nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES + RAY_BYTES + HIT_BYTES
-        # SIMD divergence of the traversal kernel, counted live by its instrumented build (same workload): lanes that
-        # take part in a node block / triangle block out of the wave's 64
         ws = ist["wave_sched"]          # wave iterations, node blocks, lanes in them, triangle blocks, lanes in them, refills
         divergence = dict(node_block_lanes=round(ws[2] / max(1, ws[1]) / 64.0, 4), tri_block_lanes=round(ws[4] / max(1, ws[3]) / 64.0, 4),
                           node_blocks_per_iteration=round(ws[1] / max(1, ws[0]), 4), tri_blocks_per_iteration=round(ws[3] / max(1, ws[0]), 4),
                           source="instrumented k_extend<stats> on one untimed step of the same workload")
+        ph = ist["extend_phase_cycles"]
+        ph_tot = float(sum(ph)) or 1.0
+        phases = {n: round(c / ph_tot, 4) for n, c in zip(PHASE_NAMES, ph)}
         launches = max(1, st["extend_launches"])
         rays_per_launch = st["rays"] / launches
-        avg_launch_s = st["extend_ms"] * 1e-3 / launches
-        achieved = bytes_per_ray * rays_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        avg_launch_s = st["extend_ms"] * 1e-3 / launches        # HIP events on the chunk's own stream around every k_extend launch of the timed region
+        # what binds the kernel is vector-ALU work, not memory: algorithmic lane-operations per ray
+        # from SURVEY.md 8d -- 112 per 8-wide node visit, 60 per triangle test -- against the fp32 vector peak
+        # (157.3 TFLOP/s = 78.65 T lane-FMAs/s, MI355X_MICROARCH.md "Peak FP32 (vector)"), one lane-op counted as one FMA slot = 2 FLOP
+        lane_ops_per_ray = nodes_per_ray * LANE_OPS_NODE + tris_per_ray * LANE_OPS_TRI
+        achieved_tflops = lane_ops_per_ray * 2.0 * rays_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+        bytes_per_ray = nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES + RAY_BYTES + HIT_BYTES
+        req_gbs = bytes_per_ray * rays_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         traffic = None
+        tcc_hit = None
         if os.path.exists(args.traffic_json):
             try:
                 tj = json.load(open(args.traffic_json))
                 if tj.get("workload") == args.workload:
-                    # PMC passes run on a shorter job; scale the measured HBM bytes per ray to this run's launch size
+                    # PMC passes run on a shorter job; scale the measured HBM-side bytes per ray to this run's launch size
                     traffic = round(tj["hbm_bytes_per_ray"] * rays_per_launch, 1)
+                    tcc_hit = tj.get("tcc_hit_rate")
             except Exception:
                 traffic = None
         valu = None
@@ -257,29 +274,49 @@ def main():
                 d = json.load(open(vj))
                 if d.get("workload") == args.workload:
                     k = d["kernels"].get("k_extend<false, false>") or d["kernels"]["k_extend<false>"]
-                    valu = dict(busy=round(k["valu_busy"], 4), lane_util=round(k["lane_util"], 4), residency=round(k["residency"], 4),
-                                source="profiles/valu.json (rocprofv3 --pmc, same workload and launch size)")
+                    valu = {x: (round(y, 4) if isinstance(y, float) else y) for x, y in k.items() if x != "counters"}
+                    valu["source"] = d.get("source", "profiles/valu.json")
+                    valu["definitions"] = d.get("definitions")
             except Exception:
                 valu = None
-        roofline = dict(bound="hbm", kernel="k_extend", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
-                        algorithmic_bytes_per_ray=round(bytes_per_ray, 1), nodes_per_ray=round(nodes_per_ray, 2),
+        # HBM view: the traversal-free floor of SURVEY.md 8d (reference data layouts: 212 B (+4 B texel) per hit ray, 32 B of
+        # accumulation per sample) against 8 TB/s, and the measured HBM-side bytes of the kernel (PMC) against the same peak
+        floor_bytes_per_sample = (st["hits"] * 216.0 + st["samples"] * 32.0) / max(1, st["samples"])
+        samples_per_s = job_samples / elapsed
+        hbm = dict(peak=HBM_PEAK_GBS, unit="GB/s",
+                   floor_bytes_per_sample=round(floor_bytes_per_sample, 1),
+                   floor_achieved=round(floor_bytes_per_sample * samples_per_s / world / 1e9, 2),
+                   floor_frac=round(floor_bytes_per_sample * samples_per_s / world / 1e9 / HBM_PEAK_GBS, 5),
+                   counter_bytes_per_launch=traffic,
+                   counter_achieved=round(traffic / avg_launch_s / 1e9, 2) if traffic and avg_launch_s > 0 else None,
+                   counter_frac=round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 5) if traffic and avg_launch_s > 0 else None,
+                   note="the 48 MB scene + BVH are served from L2 / Infinity Cache: HBM does not bound this kernel")
+        l2 = dict(peak=L2_PEAK_GBS, unit="GB/s", requested_bytes_per_ray=round(bytes_per_ray, 1), requested=round(req_gbs, 2),
+                  frac=round(req_gbs / L2_PEAK_GBS, 5), tcc_hit_rate=tcc_hit,
+                  note="bytes the kernel asks of the memory pipe (nodes x 80 + triangles x 60 + 40 per ray); part is served by the CU's L1")
+        roofline = dict(bound="valu", kernel="k_extend", achieved=round(achieved_tflops, 3), peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(achieved_tflops / VALU_PEAK_TFLOPS, 5), traffic=traffic,
+                        algorithmic_lane_ops_per_ray=round(lane_ops_per_ray, 1), nodes_per_ray=round(nodes_per_ray, 2),
                         tris_per_ray=round(tris_per_ray, 2), rays_per_launch=round(rays_per_launch, 1),
                         avg_launch_ms=round(avg_launch_s * 1e3, 4), launches=int(launches),
-                        extend_ms=round(st["extend_ms"], 2), shade_ms=round(st["shade_ms"], 2),
-                        valu=valu, divergence=divergence,
-                        note="frac > 1 is not an error: the algorithmic bytes count every node and triangle a ray touches, and the "
-                             "scene + BVH (48 MB) are served from L2 / Infinity Cache, so measured HBM traffic (`traffic`) is far below "
-                             "them and HBM does not bound this kernel.  VALU issue does: `valu.busy` = fraction of SIMD issue slots "
-                             "spent on VALU instructions (DESIGN.md section 5)")
+                        extend_ms=round(st["extend_ms"], 2),
+                        valu_issue=valu, hbm=hbm, l2=l2, divergence=divergence, wave_lifetime_by_phase=phases,
+                        note="bound = vector ALU: `frac` prices SURVEY 8d's algorithmic lane-ops (112 per node visit, 60 per triangle "
+                             "test; 1 lane-op = 1 FMA slot = 2 FLOP) against the 157.3 TFLOP/s fp32 vector peak.  The instructions the "
+                             "kernel really issues, priced with the per-class issue costs measured on this chip "
+                             "(profiles/r02_valu_calibration.json), are in `valu_issue`; HBM and L2 are side fields: neither binds.")
 
         # second kernel: k_shade streams the ray queues (HBM) and gathers one 128-byte record per hit (L2 / Infinity Cache).
         # algorithmic bytes: ray 48 + hit 8 read per ray; ShadeRec 128 (+4 texel) per hit ray; 64 written per surviving
-        # ray; 16 per terminated path (every path terminates once: survivors = rays - samples)
-        shade_bytes = st["rays"] * 56.0 + st["hits"] * 132.0 + (st["rays"] - st["samples"]) * 64.0 + st["samples"] * 16.0
-        shade = dict(bound="hbm", kernel="k_shade", achieved=round(shade_bytes / (st["shade_ms"] * 1e-3) / 1e9, 2) if st["shade_ms"] > 0 else 0.0,
-                     peak=HBM_PEAK_GBS, unit="GB/s", algorithmic_bytes_per_ray=round(shade_bytes / max(1, st["rays"]), 1),
-                     note="HIP-event time of every k_shade launch of the timed region; overlapping launches of the other chunk in flight inflate it slightly")
+        # ray; 16 per terminated path (every path terminates once: survivors = rays - samples).  Time: the shading
+        # launches of the serial instrumented step above (their own time), one step's worth of the same rays.
+        irays, ihits, isamp = ist["rays"], ist["hits"], ist["samples"]
+        shade_bytes = irays * 56.0 + ihits * 132.0 + (irays - isamp) * 64.0 + isamp * 16.0
+        shade = dict(bound="hbm", kernel="k_shade" if not lit else "k_shade_lit",
+                     achieved=round(shade_bytes / (ist["shade_ms"] * 1e-3) / 1e9, 2) if ist["shade_ms"] > 0 else 0.0,
+                     peak=HBM_PEAK_GBS, unit="GB/s", algorithmic_bytes_per_ray=round(shade_bytes / max(1, irays), 1),
+                     ms_per_step=round(ist["shade_ms"], 3),
+                     note="HIP-event time of the shading launches of ONE untimed step with every chunk on one stream (nothing overlaps them)")
         shade["frac"] = round(shade["achieved"] / HBM_PEAK_GBS, 5)
         roofline["second_kernel"] = shade
 

@@ -254,7 +254,9 @@ int ptx_import_albedo_device(ptx_context *ctx, const void *device_src, uint64_t 
 int ptx_reduce_accumulation(ptx_context **ctxs, int n, int root);
 
 int ptx_synchronize(ptx_context *ctx);
-int ptx_set_profiling(ptx_context *ctx, int level);     /* 0 off; 1 HIP-event timing of each stage launch; 2 also the instrumented traversal kernel (slower) */
+int ptx_set_profiling(ptx_context *ctx, int level);     /* 0 off; 1 HIP-event timing of each stage launch (chunks still overlap on two streams, so a stage's
+                                                           time includes waiting behind the other chunk's kernels); 2 also the instrumented traversal kernel
+                                                           (slower) with every chunk on one stream, so that shade_ms is the shading kernels' own time */
 int ptx_get_stats(ptx_context *ctx, ptx_stats *stats);  /* synchronises */
 int ptx_reset_stats(ptx_context *ctx);
 const char *ptx_last_error(ptx_context *ctx);           /* ctx may be NULL: last error of ptx_create on this thread */

@@ -987,8 +987,10 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
     for (uint32_t s0 = 0; s0 < n_samples; s0 += (uint32_t)chunk) {
         uint32_t ns = (uint32_t)std::min<uint64_t>(chunk, n_samples - s0);
         uint32_t n_paths = (uint32_t)(ns * npix);
-        PathSet &ps = c->sets[c->next_set];
-        c->next_set = (c->next_set + 1) % c->n_sets;
+        // profiling level 2 keeps every chunk on ONE path set (one stream): the HIP-event time of a stage launch is
+        // then that kernel's own time, not its time plus the wait behind the other set's persistent traversal kernel
+        PathSet &ps = c->sets[c->count_traversal ? 0 : c->next_set];
+        c->next_set = c->count_traversal ? 0 : (c->next_set + 1) % c->n_sets;
         if (int r = ensure_paths(c, ps, chunk * npix, lit)) return r;
         hipStream_t st = ps.stream;
         // queue lengths of finished chunks (any set)

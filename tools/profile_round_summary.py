@@ -27,16 +27,45 @@ traffic = {"workload": "sponza_1080p",
            "corrections": "FETCH_SIZE KiB x1024 x2 (gfx950 counts 128-B requests as 64 B for 16-B-per-lane loads; divergent gathers are outside the calibrated pattern, so treat as an upper-bound estimate); WRITE_SIZE KiB x1024"}
 json.dump(traffic, open(out + "/traffic.json", "w"), indent=1)
 vp = json.loads(subprocess.check_output([sys.executable, os.path.join(here, "pmc_summary.py"), out + "/valu"]))
+# static instruction mix by issue class (tools/isa_mix.py, made where the library is built) and the measured issue costs
+mix_path = os.path.join(os.path.dirname(here), "profiles", "r02_isa_mix.json")
+static_mix = json.load(open(mix_path))["kernels"] if os.path.exists(mix_path) else {}
 valu = {"workload": "sponza_1080p",
-        "source": "rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU, tools/prof_run.py 16 (one 16-spp batch, the bench's launch size), round tag %s" % tag,
-        "definitions": "cycles = GRBM_GUI_ACTIVE / 8 XCDs; valu_busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles): fraction of SIMD issue slots spent on VALU; residency = SQ_WAVE_CYCLES x 4 / (waves_per_simd x 1024 x cycles); lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)",
+        "source": "rocprofv3 --pmc, two passes over tools/prof_run.py 16 (one 16-spp batch, the bench's launch size): SQ_WAVES SQ_WAVE_CYCLES "
+                  "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY | SQ_INSTS_VALU "
+                  "and its _FMA_F32 _ADD_F32 _MUL_F32 _CVT _INT32 _TRANS_F32 _INT64 breakdown; round tag %s" % tag,
+        "definitions": "cycles = GRBM_GUI_ACTIVE / 8 XCDs.  Issue model measured on this chip (profiles/r02_valu_calibration.json): a SIMD has two vector "
+                       "pipes; a wave64 instruction holds one for 4 cycles; full-rate instructions (fp32 fma / add / mul, bitwise, integer add, right shifts, "
+                       "with VGPR / literal operands) can use either pipe, all others only one; transcendentals hold it for 8.  SQ_ACTIVE_INST_VALU counts 1 "
+                       "(transcendental: 2) per instruction in units of 4 cycles, whatever the class -- round 1's `valu_busy` = that x 4 / SIMD cycles "
+                       "therefore reads up to 2.0 on full-rate code and is kept only as `active_x4_per_simd_cycle`.  "
+                       "two_pipe_busy = SQ_INSTS_VALU x 4 / (2 pipes x 1024 SIMDs x cycles): share of ALL vector issue capacity in use (<= 1).  "
+                       "half_rate_pipe_busy = half-rate instructions x 4 / (1024 x cycles) (<= 1): `_static_mix` prices SQ_INSTS_VALU with the "
+                       "kernel's static half-rate share (profiles/r02_isa_mix.json), `_lo` counts only conversions and transcendentals (x 2), `_hi` "
+                       "counts everything that is not an fp32 fma / add / mul.  residency = SQ_WAVE_CYCLES x 4 / (waves_per_simd x 1024 x cycles); "
+                       "lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wait_mem / wait_issue = SQ_WAIT_ANY / SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES",
         "kernels": {}}
-for k, waves in ((EXT, 7), (SHD, 8)):   # resident waves per SIMD: 66-70 VGPRs -> 7 (pinned by amdgpu_waves_per_eu); 56 VGPRs, 512-thread blocks -> 8
+for k, waves in ((EXT, 7), (SHD, 5)):   # resident waves per SIMD: k_extend 71 VGPRs, pinned to 7 by amdgpu_waves_per_eu; k_shade 89 VGPRs in 512-thread blocks -> 5
+    if k not in vp:
+        continue
     v = {c: d["sum"] for c, d in vp[k].items()}
     cyc = v["GRBM_GUI_ACTIVE"] / 8.0
-    valu["kernels"][k] = {"counters": v, "cycles": cyc, "valu_busy": v["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cyc),
-                          "residency": v["SQ_WAVE_CYCLES"] * 4 / (waves * 1024 * cyc),
-                          "lane_util": v["SQ_THREAD_CYCLES_VALU"] / (64 * v["SQ_ACTIVE_INST_VALU"]), "waves_per_simd": waves}
+    simd_cyc = 1024.0 * cyc
+    insts = v["SQ_INSTS_VALU"]
+    share = static_mix.get(k, {}).get("half_rate_share")
+    fast_fp = v.get("SQ_INSTS_VALU_FMA_F32", 0.0) + v.get("SQ_INSTS_VALU_ADD_F32", 0.0) + v.get("SQ_INSTS_VALU_MUL_F32", 0.0)
+    e = {"counters": v, "cycles": cyc, "waves_per_simd": waves,
+         "insts_per_simd_cycle": insts / simd_cyc,
+         "two_pipe_busy": insts * 4.0 / (2.0 * simd_cyc),
+         "half_rate_pipe_busy_static_mix": (insts * share * 4.0 / simd_cyc) if share is not None else None,
+         "half_rate_pipe_busy_lo": (v.get("SQ_INSTS_VALU_CVT", 0.0) + 2.0 * v.get("SQ_INSTS_VALU_TRANS_F32", 0.0)) * 4.0 / simd_cyc,
+         "half_rate_pipe_busy_hi": (insts - fast_fp) * 4.0 / simd_cyc if fast_fp else None,
+         "static_half_rate_share": share,
+         "active_x4_per_simd_cycle": v["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cyc,
+         "residency": v["SQ_WAVE_CYCLES"] * 4.0 / (waves * simd_cyc),
+         "lane_util": v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]),
+         "wait_mem": v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"], "wait_issue": v.get("SQ_WAIT_INST_ANY", 0.0) / v["SQ_WAVE_CYCLES"]}
+    valu["kernels"][k] = e
 json.dump(valu, open(out + "/valu.json", "w"), indent=1)
 print(json.dumps({"trace_timed_region": ts.get("k_extend_timed_region", {}).get("avg_ms"), "hbm_bytes_per_ray": traffic["hbm_bytes_per_ray"],
                   "valu": {k: {x: round(y, 4) for x, y in d.items() if x != "counters"} for k, d in valu["kernels"].items()}}))
