@@ -43,6 +43,7 @@ struct PathSet {
     HitOut *d_hits = nullptr;
     float4 *d_results = nullptr;
     uint32_t *d_counters = nullptr;
+    uint32_t *d_order = nullptr, *d_class_count = nullptr;   // material sorting option of the lit integrator (allocated on first use)
     hipEvent_t resolved = nullptr;                   // recorded after the set's latest resolve
     hipEvent_t first_shade = nullptr;                // recorded after the set's latest bounce-0 shading (G-buffer / id image writes)
     // queue lengths of the set's latest chunk, copied to page-locked host memory behind the chunk (never waited for)
@@ -146,6 +147,7 @@ struct ptx_context {
     uint32_t frac_bounces = 0;
     float live_frac[kMaxDepthLimit] = {};
     uint32_t tail_shift = 7;                // ... or below 1/128 of the chunk's paths (PTX_TAIL_SHIFT): big batches hand over earlier
+    bool material_sort = false;             // PTX_MATERIAL_SORT=1: the lit integrator groups each bounce's queue by material class before shading (measured option)
     uint32_t tail_rays = 65536;             // PTX_TAIL_RAYS: expected queue length at or below which the tail takes over; 0: never
     hipEvent_t last_resolved = nullptr;     // = sets[k].resolved of the most recent chunk: the next resolve waits for it
     hipEvent_t last_first_shade = nullptr;  // = sets[k].first_shade of the most recent chunk: the next bounce-0 shading waits for it
@@ -188,7 +190,7 @@ template <class T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; }
 
 void free_paths(PathSet &ps)
 {
-    dfree(ps.d_rays[0]); dfree(ps.d_rays[1]); dfree(ps.d_rays[2]); dfree(ps.d_hits); dfree(ps.d_results);
+    dfree(ps.d_rays[0]); dfree(ps.d_rays[1]); dfree(ps.d_rays[2]); dfree(ps.d_hits); dfree(ps.d_results); dfree(ps.d_order);
     ps.capacity = 0;
 }
 
@@ -213,6 +215,8 @@ int ensure_paths(ptx_context *c, PathSet &ps, uint64_t n, bool shadow_queue)
         ps.capacity = n;
     }
     if (shadow_queue && !ps.d_rays[2]) HIP_TRY(c, hipMalloc(&ps.d_rays[2], ps.capacity * kRayBytes));
+    if (shadow_queue && c->material_sort && !ps.d_order) HIP_TRY(c, hipMalloc((void **)&ps.d_order, ps.capacity * sizeof(uint32_t)));
+    if (shadow_queue && c->material_sort && !ps.d_class_count) HIP_TRY(c, hipMalloc((void **)&ps.d_class_count, 8 * sizeof(uint32_t)));
     return PTX_OK;
 }
 
@@ -418,6 +422,7 @@ int ptx_create_with_limits(int device_ordinal, const ptx_limits *limits, ptx_con
     }
     if (const char *ts = getenv("PTX_TAIL_SHIFT")) { long v = strtol(ts, nullptr, 10); if (v >= 0 && v <= 31) c->tail_shift = (uint32_t)v; }
     if (const char *tr = getenv("PTX_TAIL_RAYS")) { long v = strtol(tr, nullptr, 10); if (v >= 0) c->tail_rays = (uint32_t)std::min<long>(v, 1 << 24); }
+    if (const char *ms = getenv("PTX_MATERIAL_SORT")) c->material_sort = atoi(ms) != 0;
     if (const char *fi = getenv("PTX_FRAMES_IN_FLIGHT")) { long v = strtol(fi, nullptr, 10); if (v >= 1 && v <= kMaxSets) c->n_sets = (int)v; }
     CREATE_TRY(hipMalloc((void **)&c->d_totals, kNumTotals * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->d_totals, 0, kNumTotals * sizeof(uint64_t)));
@@ -449,7 +454,7 @@ int ptx_destroy(ptx_context *c)
     for (int i = 0; i < kMaxSets; ++i) {
         PathSet &ps = c->sets[i];
         free_paths(ps);
-        dfree(ps.d_counters);
+        dfree(ps.d_counters); dfree(ps.d_class_count);
         if (ps.resolved) (void)hipEventDestroy(ps.resolved);
         if (ps.first_shade) (void)hipEventDestroy(ps.first_shade);
         if (ps.counts_ready) (void)hipEventDestroy(ps.counts_ready);
@@ -1037,7 +1042,12 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
             if (!lit) {
                 launch_shade(st, sc, f, img, b, rin, ps.d_hits, ps.d_counters, n_paths, rout, ps.d_results);
             } else {
-                launch_shade_lit(st, sc, f, img, b, rin, ps.d_hits, ps.d_counters, n_paths, rout, shadow_q, ps.d_results);
+                const uint32_t *order = nullptr;
+                if (c->material_sort) {
+                    launch_material_sort(st, sc, ps.d_hits, ps.d_counters + b, n_paths, ps.d_class_count, ps.d_order);
+                    order = ps.d_order;
+                }
+                launch_shade_lit(st, sc, f, img, b, rin, ps.d_hits, ps.d_counters, n_paths, rout, shadow_q, ps.d_results, order);
             }
             if (b == 0) { HIP_TRY(c, hipEventRecord(ps.first_shade, st)); c->last_first_shade = ps.first_shade; }
             e2.end(st);

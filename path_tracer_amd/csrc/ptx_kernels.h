@@ -149,7 +149,11 @@ void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const Im
 // `shadow` (count in counters[kShadowCount + depth]); radiance is accumulated in results[path].
 void launch_shade_lit(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
                       RayQueue rays_in, const HitOut *hits, uint32_t *counters, uint32_t capacity, RayQueue rays_out,
-                      RayQueue shadow, float4 *results);
+                      RayQueue shadow, float4 *results, const uint32_t *order = nullptr /* k_material_sort's permutation */);
+// Material sorting option of the lit integrator: order[0 .. *count) = the queue positions grouped by the material class of
+// their hit (sky, opaque, transmissive); class_count: 6 words of scratch
+void launch_material_sort(hipStream_t s, const SceneDev &sc, const HitOut *hits, const uint32_t *count, uint32_t capacity,
+                          uint32_t *class_count, uint32_t *order);
 // adds the contribution of every unoccluded occlusion ray of bounce `depth` to its path's radiance
 void launch_shadow_resolve(hipStream_t s, uint32_t depth, RayQueue shadow, const HitOut *hits, const uint32_t *counters,
                            uint32_t capacity, float4 *results);

@@ -781,10 +781,13 @@ __device__ __forceinline__ uint32_t block_reserve(bool flag, const BlockScan &bs
     return slot;
 }
 
+// `order` (optional): the queue positions grouped by the material class of their hit (k_material_sort): thread s of
+// the launch then shades ray order[s], so that a wave holds one kind of work -- sky, opaque lobes, glass.
 __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev f, ImagesDev img, uint32_t depth,
                                                             RayQueue rays_in, const HitOut *__restrict__ hits,
                                                             uint32_t *__restrict__ counters, uint32_t capacity,
-                                                            RayQueue rays_out, RayQueue shadow, float4 *__restrict__ results)
+                                                            RayQueue rays_out, RayQueue shadow, float4 *__restrict__ results,
+                                                            const uint32_t *__restrict__ order)
 {
     __shared__ float s_lut[256];
     __shared__ TexDesc s_tex[kLdsTextures];
@@ -802,7 +805,9 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
             reinterpret_cast<uint32_t *>(s_tex)[w] = reinterpret_cast<const uint32_t *>(sc.textures)[w];
     }
     for (uint32_t tile = blockIdx.x; (uint64_t)tile * kShadeBlock < n_live; tile += gridDim.x) {
-    const uint32_t i = tile * kShadeBlock + threadIdx.x;
+    const uint32_t slot_in = tile * kShadeBlock + threadIdx.x;
+    const bool valid = slot_in < capacity && slot_in < n_live;
+    const uint32_t i = (order && valid) ? order[slot_in] : slot_in;
     float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
     float2 hr = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
     if (i < capacity) {
@@ -812,7 +817,6 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
         r2 = depth == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : rays_in.thr[i];
         hr = *reinterpret_cast<const float2 *>(hits + i);
     }
-    const bool valid = i < capacity && i < n_live;
     const uint32_t tri = valid ? __float_as_uint(hr.y) : 0xFFFFFFFFu;
     float4 t0 = r0, t1 = r0, t2 = r0, s0 = r0, s1 = r0, s2 = r0, s3 = r0, s4 = r0;
     if (tri != 0xFFFFFFFFu) {
@@ -1045,6 +1049,59 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
     if (threadIdx.x == 0 && s_hits) atomicAdd(&counters[kHitCounter], s_hits);      // block_reserve's barriers order the LDS adds before this read
 }
 
+// Material sorting (BASELINE.json north_star: "ballot / prefix-sum primitives drive ray-queue compaction and material
+// sorting"), measured as an option of the lit integrator (PTX_MATERIAL_SORT=1): between a bounce's
+// traversal and its shading the queue positions are grouped by what the shading stage will do with them -- class 0:
+// the ray left the scene (sky), 1: opaque material (Lambert + GGX lobes, next-event estimation), 2: transmissive
+// material (glass lobe).  Per block: wave64 ballots rank the lanes of each class, the block's waves are scanned through
+// LDS, one atomic per class and block reserves a run of that class's segment.  The result is a permutation
+// (order[0 .. n)): class 0 positions first, then class 1, then class 2 -- the segment bases come from a first counting
+// launch (kCount = true), the scatter from a second.
+constexpr uint32_t kSortClasses = 3;
+template <bool kCount>
+__global__ void __launch_bounds__(kShadeBlock) k_material_sort(SceneDev sc, const HitOut *__restrict__ hits, const uint32_t *__restrict__ count,
+                                                                uint32_t *__restrict__ class_count /* [3] totals, [3] cursors */,
+                                                                uint32_t *__restrict__ order)
+{
+    __shared__ uint32_t s_cnt[kShadeBlock / 64];
+    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_class[kSortClasses];
+    const uint32_t n = *count;
+    if ((uint64_t)blockIdx.x * kShadeBlock >= n) return;
+    if (kCount) {
+        if (threadIdx.x < kSortClasses) s_class[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    for (uint32_t tile = blockIdx.x; (uint64_t)tile * kShadeBlock < n; tile += gridDim.x) {
+        const uint32_t i = tile * kShadeBlock + threadIdx.x;
+        uint32_t cls = kSortClasses;      // none
+        if (i < n) {
+            const uint32_t tri = hits[i].tri;
+            cls = 0;
+            if (tri != 0xFFFFFFFFu) cls = sc.lit_materials[sc.shade[tri].material].transmission > 0.0f ? 2u : 1u;
+        }
+        BlockScan bs; bs.wave_cnt = s_cnt; bs.base = &s_base;
+        if (kCount) {
+#pragma unroll
+            for (uint32_t c = 0; c < kSortClasses; ++c) {
+                const unsigned long long m = __ballot(cls == c);
+                if ((threadIdx.x & 63u) == 0 && m) atomicAdd(&s_class[c], (uint32_t)__popcll(m));      // LDS; one global atomic per class and block below
+            }
+        } else {
+            const uint32_t b1 = class_count[0], b2 = b1 + class_count[1];
+#pragma unroll
+            for (uint32_t c = 0; c < kSortClasses; ++c) {
+                const uint32_t slot = block_reserve(cls == c, bs, &class_count[kSortClasses + c]);
+                if (cls == c) order[(c == 0 ? 0u : (c == 1 ? b1 : b2)) + slot] = i;
+            }
+        }
+    }
+    if (kCount) {
+        __syncthreads();
+        if (threadIdx.x < kSortClasses && s_class[threadIdx.x]) atomicAdd(&class_count[threadIdx.x], s_class[threadIdx.x]);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_shadow_resolve(uint32_t depth, RayQueue shadow, const HitOut *__restrict__ hits,
                                                         const uint32_t *__restrict__ counters, float4 *__restrict__ results)
 {
@@ -1173,13 +1230,24 @@ void launch_tail(hipStream_t s, const SceneDev &sc, const FrameDev &f, uint32_t 
 
 void launch_shade_lit(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
                       RayQueue rays_in, const HitOut *hits, uint32_t *counters, uint32_t capacity, RayQueue rays_out,
-                      RayQueue shadow, float4 *results)
+                      RayQueue shadow, float4 *results, const uint32_t *order)
 {
     uint32_t blocks = (capacity + kShadeBlock - 1u) / kShadeBlock;
     if (!blocks) return;
     blocks = std::min(blocks, shade_grid_cap());
     hipLaunchKernelGGL(k_shade_lit, dim3(blocks), dim3(kShadeBlock), 0, s, sc, f, img, depth, rays_in, hits, counters,
-                       capacity, rays_out, shadow, results);
+                       capacity, rays_out, shadow, results, order);
+}
+
+void launch_material_sort(hipStream_t s, const SceneDev &sc, const HitOut *hits, const uint32_t *count, uint32_t capacity,
+                          uint32_t *class_count, uint32_t *order)
+{
+    uint32_t blocks = (capacity + kShadeBlock - 1u) / kShadeBlock;
+    if (!blocks) return;
+    blocks = std::min(blocks, shade_grid_cap());
+    (void)hipMemsetAsync(class_count, 0, 2 * kSortClasses * sizeof(uint32_t), s);
+    hipLaunchKernelGGL((k_material_sort<true>), dim3(blocks), dim3(kShadeBlock), 0, s, sc, hits, count, class_count, order);
+    hipLaunchKernelGGL((k_material_sort<false>), dim3(blocks), dim3(kShadeBlock), 0, s, sc, hits, count, class_count, order);
 }
 
 void launch_shadow_resolve(hipStream_t s, uint32_t depth, RayQueue shadow, const HitOut *hits, const uint32_t *counters,

@@ -272,3 +272,28 @@ def test_host_metallic_roughness_texture(oracle, tmp_path):
     with pytest.raises(capi.PtxError):
         ctx.set_material_ext(0, e)                       # sRGB texture refused
     ctx.close()
+
+
+def test_material_sort_option_changes_nothing_but_the_order(oracle, monkeypatch):
+    """PTX_MATERIAL_SORT=1: between traversal and shading the lit integrator groups the queue
+    by material class (sky / opaque / glass) with ballot + block-scan ranks.  Only the order in which rays are shaded
+    changes: images, ids and the ray / hit / occlusion-ray counts must equal the oracle's bit for bit -- on the lit
+    Cornell box (glass + metal + emitter) and on the stress scene with hundreds of emitters."""
+    from path_tracer_amd import capi
+    monkeypatch.setenv("PTX_MATERIAL_SORT", "1")
+    ing = cornell_lit()
+    ctx = capi.Context(0)
+    upload(ctx, ing, oracle, options=capi.SCENE_WORLD_NORMALS | capi.SCENE_TEXTURE_TIMES_FACTOR, with_material_ext=True)
+    sc = oracle.scene_from_ingest(ing, options=oracle.SCENE_WORLD_NORMALS | oracle.SCENE_TEXTURE_TIMES_FACTOR, with_material_ext=True)
+    cam = cam_cornell(oracle, 200 / 136)
+    want = sc.render(cam, 200, 136, 5, SEED, params=oracle.default_params(integrator=oracle.INTEGRATOR_LIT))
+    ctx.reset_stats()
+    got = gpu_render(ctx, oracle, cam, 200, 136, 5, params=capi.default_params(integrator=capi.INTEGRATOR_LIT))
+    assert_images_bit_equal(got, want, "lit cornell, material sort on")
+    st = ctx.stats()
+    assert st["rays"] == want["stats"]["rays"] and st["hits"] == want["stats"]["hits"] and st["shadow_rays"] == want["stats"]["shadow_rays"]
+    # the reference integrator ignores the option
+    want_ref = sc.render(cam, 200, 136, 2, SEED)
+    got_ref = gpu_render(ctx, oracle, cam, 200, 136, 2)
+    assert_images_bit_equal(got_ref, want_ref, "reference integrator, material sort env set")
+    ctx.close()
