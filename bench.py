@@ -345,6 +345,7 @@ def main():
             "rays_per_sample": round(job_rays / max(1.0, job_samples), 3),
             "shadow_rays_per_sample": round(st["shadow_rays"] / max(1, st["samples"]), 3), "lights": int(st["lights"]),
             "scene_load_s": round(load_s, 2),
+            "tail_launches": int(st["tail_launches"]),       # chunks of the timed region whose last bounces ran as one fused launch (short-path scenes)
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity": parity,
@@ -423,7 +424,8 @@ def cpu_baseline(r, wl, assets, W, H, spp, max_depth, workload, lit):
     a = np.asarray(got, np.float64)[..., :3]
     b = np.asarray(want["albedo"], np.float64)[..., :3]
     rel_mse = float(np.mean((a - b) ** 2 / (b * b + 1e-2)))
-    parity = {"spp": spp, "primary_ids_bit_exact": bool(np.array_equal(ids, want["ids"])),
+    parity = {"checked_against": "oracle/pt_oracle.c, the CPU restatement of the reference's shaders (a port: parity with the Vulkan reference itself is unpinned -- it has no fixtures and cannot run here)",
+              "spp": spp, "primary_ids_bit_exact": bool(np.array_equal(ids, want["ids"])),
               "albedo_bit_exact": bool(np.array_equal(got.view(np.uint32), want["albedo"].view(np.uint32))),
               "rel_mse": rel_mse, "rel_mse_eps": 1e-2}
     cpu = {"value": round(want["stats"]["samples"] / dt, 1), "unit": "samples/s", "cores": threads, "kind": "port",

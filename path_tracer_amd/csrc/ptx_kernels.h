@@ -127,7 +127,7 @@ constexpr uint64_t kMaxSceneTriangles = (1ull << kTriIndexBits) - 1ull;
 
 // traversal stack: entries held in LDS per lane, remainder in private memory
 #ifndef PTX_LDS_STACK
-#define PTX_LDS_STACK 8
+#define PTX_LDS_STACK 7      // 7 x 8 B x 64 lanes = 3.5 KB of the traversal kernel's 5 KB-per-wave LDS budget (8 waves per SIMD)
 #endif
 constexpr int kLdsStack = PTX_LDS_STACK;
 constexpr int kOvfStack = 32 - PTX_LDS_STACK;

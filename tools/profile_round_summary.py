@@ -45,7 +45,7 @@ valu = {"workload": "sponza_1080p",
                        "counts everything that is not an fp32 fma / add / mul.  residency = SQ_WAVE_CYCLES x 4 / (waves_per_simd x 1024 x cycles); "
                        "lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wait_mem / wait_issue = SQ_WAIT_ANY / SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES",
         "kernels": {}}
-for k, waves in ((EXT, 7), (SHD, 5)):   # resident waves per SIMD: k_extend 71 VGPRs, pinned to 7 by amdgpu_waves_per_eu; k_shade 89 VGPRs in 512-thread blocks -> 5
+for k, waves in ((EXT, 8), (SHD, 5)):   # resident waves per SIMD: k_extend 64 VGPRs, pinned to 8 by amdgpu_waves_per_eu; k_shade 89 VGPRs in 512-thread blocks -> 5
     if k not in vp:
         continue
     v = {c: d["sum"] for c, d in vp[k].items()}
