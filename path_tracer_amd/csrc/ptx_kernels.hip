@@ -91,9 +91,9 @@ __global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, Ra
 //  * Nodes are loaded straight into registers; what pays is occupancy without register spills -- 8 waves/SIMD
 //    at 64 VGPRs and 4.9 KB of LDS per wave (the 25 overflow entries of the traversal stack are a private
 //    array: 208 B of scratch per lane, touched only by rays that nest deeper than 7 groups).  At that
-//    occupancy the kernel uses 58 % of the SIMDs' vector issue capacity (profiles/valu.json, priced with
-//    the per-class issue costs of profiles/r02_valu_calibration.json); a third of a wave's life is waiting
-//    for memory, a third waiting for an issue slot.
+//    occupancy the kernel uses 62 % of the SIMDs' vector issue capacity (profiles/valu.json, priced with
+//    the per-class issue costs of profiles/r02_valu_calibration.json); 30 % of a wave's life is waiting
+//    for memory, 43 % waiting for an issue slot.
 // Traversal stack of one lane: the first kLdsStack entries in the wave's LDS block (column
 // `lane`), the rest in a private array.  The private array is referenced through a pointer so that
 // `sp` and the LDS column stay in registers (a struct holding the array itself is demoted to
@@ -180,7 +180,6 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
     __shared__ uint32_t s_qtri[kTriQueue];      // pending (triangle, owner lane) pairs: triangle index | owner << kTriIndexBits
     __shared__ uint8_t s_claim[kExtendBlock];
     __shared__ float s_dir[3][kExtendBlock];      // direction of each lane's ray: the triangle block reads its pair owner's
-    __shared__ uint32_t s_touch[16];              // landing zone of the ray-queue prefetch (never read)
     const uint32_t n = *count;
     const uint32_t lane_id = threadIdx.x;
     uint2 ovf_store[kOvfStack];
@@ -259,22 +258,6 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                                 chunk_next = lo + off;
                                 chunk_end = (len - off < chunk) ? lo + len : lo + off + chunk;
                                 got = true;
-#ifndef PTX_NO_QUEUE_PREFETCH
-                                // The chunk's rays stream in from HBM once; the ~9 refills that consume it would each
-                                // wait for that.  One dword of every 128-byte line of the chunk's first 128 rays (16 B
-                                // per ray and plane: 8 rays per line) is pulled now, by LDS-DMA into a 64-byte landing
-                                // zone nobody reads -- no VGPR is tied up -- so that later refills find the lines in L2.
-                                {
-                                    const uint32_t li = chunk_next + lane_id * 8u;
-                                    if (lane_id < 16u && li < chunk_end) {
-                                        typedef __attribute__((address_space(1))) const void gptr_t;
-                                        typedef __attribute__((address_space(3))) void lptr_t;
-                                        __builtin_amdgcn_global_load_lds((gptr_t *)(rays.inv + li), (lptr_t *)s_touch, 4, 0, 0);
-                                        __builtin_amdgcn_global_load_lds((gptr_t *)(rays.dir + li), (lptr_t *)s_touch, 4, 0, 0);
-                                        if (!sched.primary) __builtin_amdgcn_global_load_lds((gptr_t *)(rays.org + li), (lptr_t *)s_touch, 4, 0, 0);
-                                    }
-                                }
-#endif
                                 break;
                             }
                         }
