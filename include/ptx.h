@@ -229,7 +229,7 @@ int ptx_render_batch(ptx_context *ctx, const ptx_uniforms *uniforms, const ptx_c
  * a file-scope device array of the library instead of buffers allocated on demand.  The call makes no hipMalloc /
  * hipFree / stream or event creation and no host allocation.  Limits: width x height <= 262 144 pixels (512 x 512),
  * PTX_INTEGRATOR_REFERENCE only; beyond that it returns PTX_ERR_CAPACITY / PTX_ERR_INVALID with a message.  Every GPU
- * the library runs on holds its copy of the array (39.98 MB) until the process ends.  All contexts of one GPU share
+ * the library runs on holds its copy of the array (31.59 MB) until the process ends.  All contexts of one GPU share
  * that GPU's array: calls that overlap on one GPU (two contexts, two threads) race -- serialise them.  Ordered with
  * the context's other render calls; asynchronous on the context's main stream. */
 int ptx_render_static(ptx_context *ctx, const ptx_uniforms *uniforms, const ptx_camera *camera,

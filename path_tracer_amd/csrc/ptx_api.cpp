@@ -57,7 +57,7 @@ struct PathSet {
 // ---- ptx_render_static: the wavefront state of one frame in memory that is never allocated at run time.
 // The two ray queues, the hit records, the per-path results and the chunk counters of a frame of up to
 // kStaticMaxPaths pixels live in ONE file-scope device array.  Every GPU the library runs on holds its own copy
-// (39.98 MB) from module load until the process ends.  In host code the array's name is only a stand-in for the
+// (31.59 MB) from module load until the process ends.  In host code the array's name is only a stand-in for the
 // symbol: its device address is looked up once per device (static_scratch_for, called from ptx_create with that
 // device current) and only that address is ever passed to a kernel.
 constexpr uint64_t kStaticMaxPaths = 512ull * 512ull;

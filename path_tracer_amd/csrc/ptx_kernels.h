@@ -10,21 +10,21 @@
 
 namespace ptx {
 
-// The ray queue of one bounce, structure-of-arrays: four planes of 16-byte elements so that a
+// The ray queue of one bounce, structure-of-arrays: three planes of 16-byte elements so that a
 // wave's loads and stores are contiguous kilobytes.
 //   plane 0: origin.xyz, path          path = sample_in_chunk * n_pixels + pixel
 //   plane 1: direction.xyz, uv_state   uv_state = hash2(floatBitsToUint(in_uv)), constant per pixel
-//   plane 2: throughput.xyz, unused    running product of attenuations (rgen.glsl:80)
-//   plane 3: 1/direction.xyz, octant   ray_slab_setup(), done by the stage that creates the ray
-// The traversal reads planes 0 and 3 per ray (and 12 B of plane 1 per triangle test), the shading
-// stage reads 0-2 and writes all four.
+//   plane 2: throughput.xyz, pdf       running product of attenuations (rgen.glsl:80); lit integrator: pdf of the direction
+// The traversal reads planes 0 and 1 when it fetches a ray (1 / direction and the octant are derived there: round 1
+// carried them through the queue as a fourth plane, 16 B written and 16 B read per ray for three reciprocals), the
+// shading stage reads and writes all three.
 struct RayQueue {
-    float4 *org, *dir, *thr, *inv;
+    float4 *org, *dir, *thr;
 };
-constexpr uint32_t kRayBytes = 64;      // per ray over the four planes
+constexpr uint32_t kRayBytes = 48;      // per ray over the three planes
 inline RayQueue make_ray_queue(void *base, uint64_t capacity)
 {
-    RayQueue q; q.org = (float4 *)base; q.dir = q.org + capacity; q.thr = q.dir + capacity; q.inv = q.thr + capacity;
+    RayQueue q; q.org = (float4 *)base; q.dir = q.org + capacity; q.thr = q.dir + capacity;
     return q;
 }
 

@@ -58,7 +58,6 @@ __global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, Ra
     float uvx = pcx / (float)f.width, uvy = pcy / (float)f.height;
     float dx = uvx * 2.0f - 1.0f, dy = uvy * 2.0f - 1.0f;
     // rgen.glsl:30-34
-    f3 origin = mk3(f.cam_origin[0], f.cam_origin[1], f.cam_origin[2]);
     f3 target = mat4_mul(f.cam.proj_inverse, dx, dy, 1.0f, 1.0f);
     f3 tn = normalize(target);
     f3 dir = normalize(mat4_mul(f.cam.view_inverse, tn.x, tn.y, tn.z, 0.0f));
@@ -66,9 +65,6 @@ __global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, Ra
     // the origin plane (camera position, path index = queue index) is not written either: bounce 0 derives it
     rays.dir[p] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(hash2(f2u(uvx), f2u(uvy))));
     // rgen.glsl:62: the throughput of a camera ray is (1, 1, 1) -- not written; the bounce-0 shading stages know it
-    float ix, iy, iz;
-    uint32_t oct = ray_slab_setup(origin, dir, ix, iy, iz);
-    rays.inv[p] = make_float4(ix, iy, iz, __uint_as_float(oct));
 }
 
 // ---------------------------------------------------------------- extend
@@ -271,9 +267,12 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                 if (!active && rank < avail) {
                     uint32_t i = chunk_next + rank;
                     const float4 r1 = rays.dir[i];
-                    const float4 r3 = rays.inv[i];
                     const float4 r0 = sched.primary ? make_float4(sched.cam_o[0], sched.cam_o[1], sched.cam_o[2], __uint_as_float(i)) : rays.org[i];
-                    bool go = tr.init_prepared(sc.n_nodes, mk3(r0.x, r0.y, r0.z), r3.x, r3.y, r3.z, __float_as_uint(r3.w), t_min, t_max, st);
+                    // 1 / direction by v_rcp_f32 (1 ulp): the box tests only have to be conservative, and the padding of
+                    // the triangle boxes (bvh_build.cpp) is orders of magnitude above that
+                    float ix, iy, iz;
+                    const uint32_t oct = ray_slab_setup_rcp(mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), ix, iy, iz);
+                    bool go = tr.init_prepared(sc.n_nodes, mk3(r0.x, r0.y, r0.z), ix, iy, iz, oct, t_min, t_max, st);
                     next_ni = go ? tr.node_pick(st) : 0xFFFFFFFFu;
                     ray = i;
                     my_tail = q_head;
@@ -527,7 +526,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
     __syncthreads();
 
     bool alive = false, was_hit = false;
-    float4 o0, o1, o2, o3;
+    float4 o0, o1, o2;
     if (valid) {
         f3 ro = mk3(r0.x, r0.y, r0.z), rd = mk3(r1.x, r1.y, r1.z);
         uint32_t path = __float_as_uint(r0.w), uv_state = __float_as_uint(r1.w);
@@ -605,9 +604,6 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
             o0 = make_float4(new_o.x, new_o.y, new_o.z, r0.w);
             o1 = make_float4(new_d.x, new_d.y, new_d.z, r1.w);
             o2 = make_float4(thr.x, thr.y, thr.z, 0.0f);
-            float ix, iy, iz;
-            uint32_t oct = ray_slab_setup(new_o, new_d, ix, iy, iz);
-            o3 = make_float4(ix, iy, iz, __uint_as_float(oct));
         }
     }
 
@@ -640,7 +636,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
     if (alive) {
         uint32_t before = wave ? s_wave_live[wave - 1] : 0u;
         uint32_t slot = s_base + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
-        rays_out.org[slot] = o0; rays_out.dir[slot] = o1; rays_out.thr[slot] = o2; rays_out.inv[slot] = o3;
+        rays_out.org[slot] = o0; rays_out.dir[slot] = o1; rays_out.thr[slot] = o2;
     }
     __syncthreads();      // the LDS scan words are reused by the next tile
     }
@@ -834,7 +830,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
     __syncthreads();
 
     bool alive = false, was_hit = false, want_shadow = false;
-    float4 o0, o1, o2, o3, q0, q1, q2, q3;
+    float4 o0, o1, o2, q0, q1, q2;
     if (valid) {
         const f3 o = mk3(r0.x, r0.y, r0.z), dir = mk3(r1.x, r1.y, r1.z);
         const uint32_t path = __float_as_uint(r0.w), uv_state = __float_as_uint(r1.w);
@@ -971,9 +967,6 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
                         q0 = make_float4(up_o.x, up_o.y, up_o.z, r0.w);
                         q1 = make_float4(dl.x, dl.y, dl.z, 0.0f);
                         q2 = make_float4(c.x, c.y, c.z, 0.0f);
-                        float ix, iy, iz;
-                        uint32_t oct = ray_slab_setup(up_o, dl, ix, iy, iz);
-                        q3 = make_float4(ix, iy, iz, __uint_as_float(oct));
                     }
                 }
 
@@ -1037,9 +1030,6 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
             o0 = make_float4(new_o.x, new_o.y, new_o.z, r0.w);
             o1 = make_float4(new_d.x, new_d.y, new_d.z, r1.w);
             o2 = make_float4(thr.x, thr.y, thr.z, next_pdf);
-            float ix, iy, iz;
-            uint32_t oct = ray_slab_setup(new_o, new_d, ix, iy, iz);
-            o3 = make_float4(ix, iy, iz, __uint_as_float(oct));
         }
     }
 
@@ -1050,9 +1040,9 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
         if ((threadIdx.x & 63u) == 0 && hitm) atomicAdd(&s_hits, (uint32_t)__popcll(hitm));
     }
     const uint32_t slot = block_reserve(alive, bs, &counters[depth + 1u]);
-    if (alive) { rays_out.org[slot] = o0; rays_out.dir[slot] = o1; rays_out.thr[slot] = o2; rays_out.inv[slot] = o3; }
+    if (alive) { rays_out.org[slot] = o0; rays_out.dir[slot] = o1; rays_out.thr[slot] = o2; }
     const uint32_t sslot = block_reserve(want_shadow, bs, &counters[kShadowCount + depth]);
-    if (want_shadow) { shadow.org[sslot] = q0; shadow.dir[sslot] = q1; shadow.thr[sslot] = q2; shadow.inv[sslot] = q3; }
+    if (want_shadow) { shadow.org[sslot] = q0; shadow.dir[sslot] = q1; shadow.thr[sslot] = q2; }
     }
     if (threadIdx.x == 0 && s_hits) atomicAdd(&counters[kHitCounter], s_hits);      // block_reserve's barriers order the LDS adds before this read
 }

@@ -83,6 +83,22 @@ PT_HD uint32_t ray_slab_setup(f3 org, f3 dir, float &ix, float &iy, float &iz)
     return oct;
 }
 
+#if defined(__HIPCC__)
+// The same with hardware reciprocals (v_rcp_f32, 1 ulp) for the stage that fetches rays on the GPU: the slab tests only
+// have to be conservative, not reproducible.
+__device__ __forceinline__ uint32_t ray_slab_setup_rcp(f3 org, f3 dir, float &ix, float &iy, float &iz)
+{
+    const float tiny = 1e-18f;
+    float dx = fabsf(dir.x) > tiny ? dir.x : copysignf(tiny, dir.x);
+    float dy = fabsf(dir.y) > tiny ? dir.y : copysignf(tiny, dir.y);
+    float dz = fabsf(dir.z) > tiny ? dir.z : copysignf(tiny, dir.z);
+    ix = __builtin_amdgcn_rcpf(dx); iy = __builtin_amdgcn_rcpf(dy); iz = __builtin_amdgcn_rcpf(dz);
+    uint32_t oct = (dx < 0.0f ? 0u : 4u) | (dy < 0.0f ? 0u : 2u) | (dz < 0.0f ? 0u : 1u);
+    if (!finite3(org) || !finite3(dir)) oct |= kRayDegenerate;
+    return oct;
+}
+#endif
+
 // Stack: any type with push(uint32_t, uint32_t), pop(uint32_t&, uint32_t&), empty(), clear().
 template <class Stack, bool kStats>
 struct Traversal {
