@@ -103,14 +103,14 @@ struct LaneStack {
     __device__ __forceinline__ void clear() { sp = 0; }
     __device__ __forceinline__ void push(uint32_t base, uint32_t mask)
     {
-        if (sp < kLdsStack) { lds[sp * kExtendBlock].x = base; lds[sp * kExtendBlock].y = mask; }
+        if (__builtin_expect(sp < kLdsStack, 1)) { lds[sp * kExtendBlock].x = base; lds[sp * kExtendBlock].y = mask; }
         else { ovf[sp - kLdsStack].x = base; ovf[sp - kLdsStack].y = mask; }
         ++sp;
     }
     __device__ __forceinline__ void pop(uint32_t &base, uint32_t &mask)
     {
         --sp;
-        if (sp < kLdsStack) { base = lds[sp * kExtendBlock].x; mask = lds[sp * kExtendBlock].y; }
+        if (__builtin_expect(sp < kLdsStack, 1)) { base = lds[sp * kExtendBlock].x; mask = lds[sp * kExtendBlock].y; }
         else { base = ovf[sp - kLdsStack].x; mask = ovf[sp - kLdsStack].y; }
     }
     __device__ __forceinline__ bool empty() const { return sp == 0; }
@@ -383,7 +383,7 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                         uint32_t rti = lane_read_u(ti, src & 63u);
                         if (src != 0xFFu) {
                             bool better = rt < tr.hit.t;
-                            if (rt == tr.hit.t) {
+                            if (__builtin_expect(rt == tr.hit.t, 0)) {
                                 // equal distance (shared edges, coincident surfaces): lowest (instance, primitive) wins
                                 const uint32_t *wa = reinterpret_cast<const uint32_t *>(sc.tris + rti);
                                 const uint32_t *wb = reinterpret_cast<const uint32_t *>(sc.tris + tr.hit.tri);
