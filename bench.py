@@ -46,8 +46,9 @@ VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md "Peak FP32 (vector)"
 LANE_OPS_NODE, LANE_OPS_TRI = 112.0, 60.0      # algorithmic lane-ops per 8-wide node visit / per watertight triangle test
 PHASE_NAMES = ["ray fetch", "node-load wait", "node test + pick", "queue append", "triangle fetch wait", "triangle test",
                "hit hand-back", "retire + loop"]
-# per node visit, per triangle test (48 B of vertices + the 12 B ray direction it re-reads), ray fetch, hit record
-NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 80, 60, 32, 8
+# per node visit, per triangle test (48 B of vertices; the ray direction it needs is in LDS since round 2), ray fetch (origin +
+# direction planes), hit record
+NODE_BYTES, TRI_BYTES, RAY_BYTES, HIT_BYTES = 80, 48, 32, 8
 
 
 def main():
@@ -293,7 +294,7 @@ def main():
                    note="the 48 MB scene + BVH are served from L2 / Infinity Cache: HBM does not bound this kernel")
         l2 = dict(peak=L2_PEAK_GBS, unit="GB/s", requested_bytes_per_ray=round(bytes_per_ray, 1), requested=round(req_gbs, 2),
                   frac=round(req_gbs / L2_PEAK_GBS, 5), tcc_hit_rate=tcc_hit,
-                  note="bytes the kernel asks of the memory pipe (nodes x 80 + triangles x 60 + 40 per ray); part is served by the CU's L1")
+                  note="bytes the kernel asks of the memory pipe (nodes x 80 + triangles x 48 + 40 per ray); part is served by the CU's L1")
         roofline = dict(bound="valu", kernel="k_extend", achieved=round(achieved_tflops, 3), peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(achieved_tflops / VALU_PEAK_TFLOPS, 5), traffic=traffic,
                         algorithmic_lane_ops_per_ray=round(lane_ops_per_ray, 1), nodes_per_ray=round(nodes_per_ray, 2),
@@ -307,11 +308,11 @@ def main():
                              "(profiles/r02_valu_calibration.json), are in `valu_issue`; HBM and L2 are side fields: neither binds.")
 
         # second kernel: k_shade streams the ray queues (HBM) and gathers one 128-byte record per hit (L2 / Infinity Cache).
-        # algorithmic bytes: ray 48 + hit 8 read per ray; ShadeRec 128 (+4 texel) per hit ray; 64 written per surviving
+        # algorithmic bytes: ray 48 + hit 8 read per ray; ShadeRec 128 (+4 texel) per hit ray; 48 written per surviving
         # ray; 16 per terminated path (every path terminates once: survivors = rays - samples).  Time: the shading
         # launches of the serial instrumented step above (their own time), one step's worth of the same rays.
         irays, ihits, isamp = ist["rays"], ist["hits"], ist["samples"]
-        shade_bytes = irays * 56.0 + ihits * 132.0 + (irays - isamp) * 64.0 + isamp * 16.0
+        shade_bytes = irays * 56.0 + ihits * 132.0 + (irays - isamp) * 48.0 + isamp * 16.0
         shade = dict(bound="hbm", kernel="k_shade" if not lit else "k_shade_lit",
                      achieved=round(shade_bytes / (ist["shade_ms"] * 1e-3) / 1e9, 2) if ist["shade_ms"] > 0 else 0.0,
                      peak=HBM_PEAK_GBS, unit="GB/s", algorithmic_bytes_per_ray=round(shade_bytes / max(1, irays), 1),
