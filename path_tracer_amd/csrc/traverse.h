@@ -185,6 +185,25 @@ struct Traversal {
         // folded into the hit mask with one three-input bit operation, instead of v_cmp + v_cndmask + v_or.
         // The half-rate pipe keeps the 48 byte conversions, 4 min / max per child and the per-child mask shifts.
         const uint32_t mx = negx ? 0xFFFFFFFFu : 0u, my = negy ? 0xFFFFFFFFu : 0u, mz = negz ? 0xFFFFFFFFu : 0u;
+#ifdef PTX_PROBE
+        // developer experiment (tools/probe_sweep.sh): 40 extra instructions per node visit of one kind -- what is the kernel sensitive to?
+        {
+            uint32_t p0 = n.w[0], p1 = n.w[1], p2 = n.w[2], p3 = n.w[3];
+#pragma unroll
+            for (int r = 0; r < 10; ++r) {
+#if PTX_PROBE == 1      // full-rate vector
+                asm volatile("v_xor_b32 %0, %0, %1\n v_xor_b32 %1, %1, %2\n v_xor_b32 %2, %2, %3\n v_xor_b32 %3, %3, %0" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+#elif PTX_PROBE == 2    // half-rate vector
+                asm volatile("v_bfe_u32 %0, %0, 1, 31\n v_bfe_u32 %1, %1, 1, 31\n v_bfe_u32 %2, %2, 1, 31\n v_bfe_u32 %3, %3, 1, 31" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+#elif PTX_PROBE == 3    // scalar
+                asm volatile("s_add_u32 s90, s90, 1\n s_add_u32 s91, s91, 1\n s_add_u32 s92, s92, 1\n s_add_u32 s93, s93, 1" : : : "s90", "s91", "s92", "s93", "scc");
+#elif PTX_PROBE == 4    // idle issue slots
+                asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");
+#endif
+            }
+            hitmask = (p0 ^ p1 ^ p2 ^ p3) == 0x12345679u ? 1u : 0u;
+        }
+#endif
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             uint32_t meta4 = n.w[6 + half];
