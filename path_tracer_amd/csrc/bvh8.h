@@ -30,7 +30,7 @@ static_assert(sizeof(Bvh8Node) == 80, "Bvh8Node must be 80 bytes");
 struct alignas(16) TriRec {
     float v0[3]; uint32_t instance;
     float v1[3]; uint32_t prim;
-    float v2[3]; uint32_t material;
+    float v2[3]; uint32_t rank;       // position in (instance, primitive) order = index in the builder's input soup: the tie-break key of equal-distance hits
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 

@@ -109,6 +109,7 @@ struct ptx_context {
     // device scene
     Bvh8Node *d_nodes = nullptr; uint32_t n_nodes = 0;
     TriRec *d_tris = nullptr; ShadeRec *d_shade = nullptr; uint64_t n_tris = 0;
+    uint32_t *d_tri_of_rank = nullptr; uint64_t cap_rank = 0;   // soup index (= TriRec::rank) -> leaf-order index; k_extend's closest hit is kept by rank
     TexDesc *d_textures = nullptr;
     float *d_lut = nullptr;
     LitMaterial *d_lit_materials = nullptr;       // lit integrator
@@ -446,7 +447,7 @@ int ptx_destroy(ptx_context *c)
     drain_events(c);
     for (EventPair &p : c->event_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (TexDesc &t : c->textures) { void *p = (void *)t.texels; if (p) (void)hipFree(p); }
-    dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_textures); dfree(c->d_lut);
+    dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_tri_of_rank); dfree(c->d_textures); dfree(c->d_lut);
     dfree(c->d_lit_materials); dfree(c->d_lights); dfree(c->d_light_cdf);
     if (c->staging) (void)hipHostFree(c->staging);
     dfree(c->d_leaf_src); dfree(c->d_vertices); dfree(c->d_refit_inst); dfree(c->d_raw_box); dfree(c->d_node_box); dfree(c->d_refit_state);
@@ -830,7 +831,7 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
         }
         TriRec &tr = tris[k];
         memcpy(tr.v0, &wv[(uint64_t)t * 9], 12); memcpy(tr.v1, &wv[(uint64_t)t * 9 + 3], 12); memcpy(tr.v2, &wv[(uint64_t)t * 9 + 6], 12);
-        tr.instance = tri_inst[t]; tr.prim = tri_prim[t]; tr.material = in.off.material_offset;
+        tr.instance = tri_inst[t]; tr.prim = tri_prim[t]; tr.rank = t;     // the soup is laid out instance by instance, primitive by primitive
         ShadeRec &sr = shade[k];
         memset(&sr, 0, sizeof sr);
         memcpy(sr.v0, tr.v0, 12); memcpy(sr.v1, tr.v1, 12); memcpy(sr.v2, tr.v2, 12);
@@ -869,6 +870,14 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
         c->cap_tris = nt;
     }
     if (c->n_nodes) HIP_TRY(c, hipMemcpyAsync(c->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(Bvh8Node), hipMemcpyHostToDevice, c->stream));
+    if (n_tris > c->cap_rank) {
+        dfree(c->d_tri_of_rank); c->cap_rank = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_tri_of_rank, n_tris * sizeof(uint32_t)));
+        c->cap_rank = n_tris;
+    }
+    std::vector<uint32_t> tri_of_rank(n_tris, 0xFFFFFFFFu);          // non-finite triangles are in no leaf: never hit
+    for (uint64_t k = 0; k < nt; ++k) tri_of_rank[bvh.tri_order[k]] = (uint32_t)k;
+    if (n_tris) HIP_TRY(c, hipMemcpyAsync(c->d_tri_of_rank, tri_of_rank.data(), n_tris * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     if (nt) {
         HIP_TRY(c, hipMemcpyAsync(c->d_tris, tris, nt * sizeof(TriRec), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->d_shade, shade, nt * sizeof(ShadeRec), hipMemcpyHostToDevice, c->stream));
@@ -968,7 +977,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
 
     SceneDev sc;
     sc.lit_materials = c->d_lit_materials; sc.lights = c->d_lights; sc.light_cdf = c->d_light_cdf; sc.n_lights = c->n_lights;
-    sc.nodes = c->d_nodes; sc.n_nodes = c->n_nodes; sc.tris = c->d_tris; sc.shade = c->d_shade;
+    sc.nodes = c->d_nodes; sc.n_nodes = c->n_nodes; sc.tris = c->d_tris; sc.shade = c->d_shade; sc.tri_of_rank = c->d_tri_of_rank;
     sc.textures = c->d_textures; sc.n_textures = c->n_dev_textures; sc.srgb_lut = c->d_lut;
     ImagesDev img; img.albedo = c->d_albedo; img.normal = c->d_normal; img.depth = c->d_depth; img.ids = c->d_ids;
     FrameDev f;
@@ -1113,7 +1122,7 @@ int ptx_render_static(ptx_context *c, const ptx_uniforms *u, const ptx_camera *c
 
     SceneDev sc;
     sc.lit_materials = c->d_lit_materials; sc.lights = c->d_lights; sc.light_cdf = c->d_light_cdf; sc.n_lights = c->n_lights;
-    sc.nodes = c->d_nodes; sc.n_nodes = c->n_nodes; sc.tris = c->d_tris; sc.shade = c->d_shade;
+    sc.nodes = c->d_nodes; sc.n_nodes = c->n_nodes; sc.tris = c->d_tris; sc.shade = c->d_shade; sc.tri_of_rank = c->d_tri_of_rank;
     sc.textures = c->d_textures; sc.n_textures = c->n_dev_textures; sc.srgb_lut = c->d_lut;
     ImagesDev img; img.albedo = c->d_albedo; img.normal = c->d_normal; img.depth = c->d_depth; img.ids = c->d_ids;
     FrameDev f;

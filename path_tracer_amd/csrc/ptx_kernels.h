@@ -78,6 +78,7 @@ constexpr uint32_t kLdsTextures = 64;   // descriptors of the first textures are
 struct SceneDev {
     const Bvh8Node *nodes; uint32_t n_nodes;
     const TriRec *tris;
+    const uint32_t *tri_of_rank;        // TriRec::rank -> index into tris / shade (k_extend keeps its closest hit by rank)
     const ShadeRec *shade;
     const TexDesc *textures; uint32_t n_textures;
     const float *srgb_lut;   // 256 floats
@@ -127,7 +128,7 @@ constexpr uint64_t kMaxSceneTriangles = (1ull << kTriIndexBits) - 1ull;
 
 // traversal stack: entries held in LDS per lane, remainder in private memory
 #ifndef PTX_LDS_STACK
-#define PTX_LDS_STACK 7      // 7 x 8 B x 64 lanes = 3.5 KB of the traversal kernel's 5 KB-per-wave LDS budget (8 waves per SIMD)
+#define PTX_LDS_STACK 6      // 6 x 8 B x 64 lanes = 3 KB of the traversal kernel's 5 KB-per-wave LDS budget (8 waves per SIMD)
 #endif
 constexpr int kLdsStack = PTX_LDS_STACK;
 constexpr int kOvfStack = 32 - PTX_LDS_STACK;

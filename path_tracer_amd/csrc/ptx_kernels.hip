@@ -204,7 +204,7 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
 {
     __shared__ uint2 s_stack[kLdsStack * kExtendBlock];
     __shared__ uint32_t s_qtri[kTriQueue];      // pending (triangle, owner lane) pairs: triangle index | owner << kTriIndexBits
-    __shared__ uint8_t s_claim[kExtendBlock];
+    __shared__ unsigned long long s_best[kExtendBlock];   // closest hit of each lane's ray as one ordered word: float bits of t << 32 | TriRec::rank
     __shared__ float s_dir[3][kExtendBlock];      // direction of each lane's ray: the triangle block reads its pair owner's
     const uint32_t n = *count;
     const uint32_t lane_id = threadIdx.x;
@@ -308,6 +308,7 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                     my_tail = q_head;
                     active = true;
                     s_dir[0][lane_id] = r1.x; s_dir[1][lane_id] = r1.y; s_dir[2][lane_id] = r1.z;
+                    s_best[lane_id] = ((unsigned long long)__float_as_uint(t_max) << 32) | 0xFFFFFFFFull;
                 }
                 uint32_t n_idle = (uint32_t)__popcll(idle);
                 chunk_next += (n_idle < avail) ? n_idle : avail;
@@ -400,32 +401,19 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                     }
                     PTX_PHASE(5);
                     q_head += nt;
-                    // hand the successful tests to their owners; two pairs of one owner take two rounds
-                    while (__ballot(cand) != 0ull) {
-                        s_claim[lane_id] = 0xFFu;
-                        wave_lds_sync();
-                        if (cand) s_claim[own] = (uint8_t)lane_id;
-                        wave_lds_sync();
-                        uint32_t src = s_claim[lane_id];
-                        bool won = cand && (uint32_t)s_claim[own] == lane_id;
-                        wave_lds_sync();
-                        float rt = lane_read_f(t, src & 63u);
-                        uint32_t rti = lane_read_u(ti, src & 63u);
-                        if (src != 0xFFu) {
-                            bool better = rt < tr.hit.t;
-                            if (__builtin_expect(rt == tr.hit.t, 0)) {
-                                // equal distance (shared edges, coincident surfaces): lowest (instance, primitive) wins
-                                const uint32_t *wa = reinterpret_cast<const uint32_t *>(sc.tris + rti);
-                                const uint32_t *wb = reinterpret_cast<const uint32_t *>(sc.tris + tr.hit.tri);
-                                uint32_t ia = wa[3], pa = wa[7], ib = wb[3], pb = wb[7];
-                                better = ia < ib || (ia == ib && pa < pb);
-                            }
-                            if (better) {
-                                tr.hit.t = rt; tr.hit.tri = rti;
-                                if (kAnyHit) { next_ni = 0xFFFFFFFFu; st.sp = 0; tr.ng_mask = 0; }
-                            }
+                    // Hand the successful tests to their owners: one LDS atomic minimum on the owner's (t, rank) word.  t is
+                    // positive, so its float bits order like the value; equal distances (shared edges, coincident surfaces)
+                    // fall through to the rank = lowest (instance, primitive) wins, the oracle's rule; several pairs of one
+                    // owner, in any order, leave the same minimum.  Then every lane reloads its own word.
+                    if (cand) atomicMin(&s_best[own], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)__float_as_uint(r2.w));
+                    wave_lds_sync();
+                    {
+                        const unsigned long long best = s_best[lane_id];
+                        const uint32_t best_rank = (uint32_t)best;
+                        if (active) {
+                            tr.hit.t = __uint_as_float((uint32_t)(best >> 32)); tr.hit.tri = best_rank;
+                            if (kAnyHit && best_rank != 0xFFFFFFFFu) { next_ni = 0xFFFFFFFFu; st.sp = 0; tr.ng_mask = 0; }
                         }
-                        cand = cand && !won;
                     }
                     PTX_PHASE(6);
                 }
@@ -435,6 +423,9 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                 if (kStats) tot_nodes += tr.stats.nodes;
                 active = false;
                 unwritten = true;
+                // the closest hit was kept by rank; the stages downstream index triangles in leaf order (an occlusion
+                // query only reports hit / miss)
+                if (!kAnyHit && tr.hit.tri != 0xFFFFFFFFu) tr.hit.tri = sc.tri_of_rank[tr.hit.tri];
             }
             PTX_PHASE(7);
         } while (__popcll(__ballot(active)) > stop_at);

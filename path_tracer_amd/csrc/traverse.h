@@ -171,7 +171,12 @@ struct Traversal {
         uint32_t ew = n.w[3];
         float sx = u2f((ew & 0xFFu) << 23), sy = u2f(((ew >> 8) & 0xFFu) << 23), sz = u2f(((ew >> 16) & 0xFFu) << 23);
         float ax = sx * idx, ay = sy * idy, az = sz * idz;            // t per quantisation step
+#if defined(__HIP_DEVICE_COMPILE__)
+        // plane times are measured from t_min (folded into the per-axis offset for free), see below
+        float bx = fma_f(px - o.x, idx, -t_min), by = fma_f(py - o.y, idy, -t_min), bz = fma_f(pz - o.z, idz, -t_min);
+#else
         float bx = (px - o.x) * idx, by = (py - o.y) * idy, bz = (pz - o.z) * idz;
+#endif
         const bool negx = !(octinv & 4u), negy = !(octinv & 2u), negz = !(octinv & 1u);
 
         uint32_t hitmask = 0;
@@ -183,8 +188,13 @@ struct Traversal {
         // v_pk_fma_f32 is two half-rate slots for two FMAs: no gain), near / far planes picked by bitfield select
         // against per-axis sign masks, and the box decision as the sign of (t_far - t_near) smeared over the word and
         // folded into the hit mask with one three-input bit operation, instead of v_cmp + v_cndmask + v_or.
-        // The half-rate pipe keeps the 48 byte conversions, 4 min / max per child and the per-child mask shifts.
+        // With times measured from t_min the box decision is: a <= b, a <= t_best - t_min and b >= 0, where a / b are the
+        // latest entry / earliest exit over the three slabs: one v_max3, one v_min3, two subtractions and the OR of three
+        // sign bits, instead of clamping a and b against t_min / t_best with two more half-rate v_max / v_min.  The limit
+        // is widened by a few ulp so that the rounding of the shifted times cannot cull a candidate at t == t_best.
+        // The half-rate pipe keeps the 48 byte conversions, v_max3 + v_min3 per child and one byte-selecting shift per child.
         const uint32_t mx = negx ? 0xFFFFFFFFu : 0u, my = negy ? 0xFFFFFFFFu : 0u, mz = negz ? 0xFFFFFFFFu : 0u;
+        const float limit = fma_f(hit.t, 1.0f + 0x1p-21f, -t_min);
 #ifdef PTX_PROBE
         // developer experiment (tools/probe_sweep.sh): 40 extra instructions per node visit of one kind -- what is the kernel sensitive to?
         {
@@ -213,7 +223,7 @@ struct Traversal {
             uint32_t nx4 = __builtin_amdgcn_bitop3_b32(qlx, qhx, mx, 0xD8), fx4 = __builtin_amdgcn_bitop3_b32(qhx, qlx, mx, 0xD8);
             uint32_t ny4 = __builtin_amdgcn_bitop3_b32(qly, qhy, my, 0xD8), fy4 = __builtin_amdgcn_bitop3_b32(qhy, qly, my, 0xD8);
             uint32_t nz4 = __builtin_amdgcn_bitop3_b32(qlz, qhz, mz, 0xD8), fz4 = __builtin_amdgcn_bitop3_b32(qhz, qlz, mz, 0xD8);
-            uint32_t inner4 = ((meta4 & (meta4 << 1)) >> 4) & 0x01010101u;      // 1 in each byte that is an inner child
+            uint32_t inner4 = ((meta4 & (meta4 + meta4)) >> 4) & 0x01010101u;   // 1 in each byte that is an inner child
             uint32_t bit4 = (meta4 ^ (inner4 * octinv)) & 0x1F1F1F1Fu;          // hit-mask bit position per child
             uint32_t cnt4 = (meta4 >> 5) & 0x07070707u;                         // unary triangle count (1 for inner)
 #pragma unroll
@@ -221,14 +231,20 @@ struct Traversal {
                 float tnx = fma_f(byte_f(nx4, k), ax, bx), tfx = fma_f(byte_f(fx4, k), ax, bx);
                 float tny = fma_f(byte_f(ny4, k), ay, by), tfy = fma_f(byte_f(fy4, k), ay, by);
                 float tnz = fma_f(byte_f(nz4, k), az, bz), tfz = fma_f(byte_f(fz4, k), az, bz);
-                float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, t_min));
-                float tf = fminf(fminf(tfx, tfy), fminf(tfz, hit.t));
-                uint32_t bits = ((cnt4 >> (8 * k)) & 0xFFu) << ((bit4 >> (8 * k)) & 0xFFu);
-                // miss = all ones iff tf - tn < 0 (the t values are finite: directions are clamped away from 0 and
-                // non-finite rays never get here; x - x is +0, so tn == tf counts as a hit like `tn <= tf`)
-                float d = tf - tn;
+                float a = fmaxf(fmaxf(tnx, tny), tnz);
+                float b = fminf(fminf(tfx, tfy), tfz);
+                // cnt << bit with both operands picked out of their words by the instruction itself
+                uint32_t bits;
+                if (k == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(bits) : "v"(bit4), "v"(cnt4));
+                if (k == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(bits) : "v"(bit4), "v"(cnt4));
+                if (k == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(bits) : "v"(bit4), "v"(cnt4));
+                if (k == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(bits) : "v"(bit4), "v"(cnt4));
+                // miss = all ones iff any of (b - a), (limit - a), b is negative (the t values are finite: directions are
+                // clamped away from 0 and non-finite rays never get here; x - x is +0, so a == b counts as a hit)
+                float d1 = b - a, d2 = limit - a;
+                uint32_t sgn = __builtin_amdgcn_bitop3_b32(__float_as_uint(d1), __float_as_uint(d2), __float_as_uint(b), 0xFE);
                 uint32_t miss;
-                asm("v_ashrrev_i32 %0, 31, %1" : "=v"(miss) : "v"(d));
+                asm("v_ashrrev_i32 %0, 31, %1" : "=v"(miss) : "v"(sgn));
                 hitmask = __builtin_amdgcn_bitop3_b32(hitmask, bits, miss, 0xF4);   // hitmask | (bits & ~miss)
             }
         }

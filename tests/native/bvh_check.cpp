@@ -34,7 +34,7 @@ void *bvhcheck_create(const float *verts, const uint32_t *ids, uint64_t n_tris, 
         uint32_t t = c->bvh.tri_order[i];
         TriRec &r = c->tris[i];
         for (int a = 0; a < 3; ++a) { r.v0[a] = verts[t * 9 + a]; r.v1[a] = verts[t * 9 + 3 + a]; r.v2[a] = verts[t * 9 + 6 + a]; }
-        r.instance = ids[t * 2]; r.prim = ids[t * 2 + 1]; r.material = 0;
+        r.instance = ids[t * 2]; r.prim = ids[t * 2 + 1]; r.rank = (uint32_t)t;
     }
     return c;
 }

@@ -103,7 +103,7 @@ int main(int argc, char **argv)
             for (size_t i = 0; i < tris.size(); ++i) {
                 uint32_t t = bvh.tri_order[i];
                 memcpy(tris[i].v0, &v[t * 9], 12); memcpy(tris[i].v1, &v[t * 9 + 3], 12); memcpy(tris[i].v2, &v[t * 9 + 6], 12);
-                tris[i].instance = 0; tris[i].prim = t; tris[i].material = 0;
+                tris[i].instance = 0; tris[i].prim = t; tris[i].rank = t;
             }
             for (int r = 0; r < 3000; ++r) {
                 HostStack st;

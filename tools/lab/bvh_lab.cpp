@@ -36,7 +36,7 @@ void lab_trace(void *h, const float *verts, const float *rays, uint64_t n, float
     for (size_t i = 0; i < tris.size(); ++i) {
         uint32_t t = bvh.tri_order[i];
         for (int a = 0; a < 3; ++a) { tris[i].v0[a] = verts[t * 9 + a]; tris[i].v1[a] = verts[t * 9 + 3 + a]; tris[i].v2[a] = verts[t * 9 + 6 + a]; }
-        tris[i].instance = 0; tris[i].prim = t; tris[i].material = 0;
+        tris[i].instance = 0; tris[i].prim = t; tris[i].rank = t;
     }
     for (int k = 0; k < 8; ++k) out[k] = 0;
     for (uint64_t i = 0; i < n; ++i) {
