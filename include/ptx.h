@@ -108,7 +108,12 @@ typedef struct {
     uint32_t mr_texture;          /* glTF metallicRoughnessTexture as bindless index + 1 (0: none), added with
                                      ptx_add_texture WITHOUT the sRGB bit: roughness = roughnessFactor x G,
                                      metallic = metallicFactor x B at the hit's uv (lit integrator only) */
-    uint32_t _pad[2];
+    uint32_t normal_texture;      /* glTF normalTexture as bindless index + 1 (0: none), a LINEAR texture: tangent-space
+                                     normal = texel x 2 - 1, +Y up; the tangent frame is derived per triangle from its
+                                     world-space positions and uvs (the vertex format has no tangent); scale taken as 1 */
+    uint32_t emissive_texture;    /* glTF emissiveTexture as bindless index + 1 (0: none), an sRGB texture: emitted
+                                     radiance = emissive x texel at the point's uv -- at a hit and at a light sample; the
+                                     light table still picks triangles by area x luminance(emissive) (lit integrator only) */
 } ptx_material_ext;
 
 typedef enum {

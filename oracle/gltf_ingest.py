@@ -25,7 +25,8 @@ OFFSETS_DTYPE = np.dtype([("vertex_offset", "<u4"), ("vertex_count", "<u4"), ("m
                           ("padding", "<u4"), ("index_offset", "<u4"), ("index_count", "<u4")])
 INSTANCE_DTYPE = np.dtype([("xform", "<f4", (3, 4)), ("geometry", "<u4"), ("off", OFFSETS_DTYPE)])
 # build extension: what glTF materials carry beyond material.rs:70-76
-MATERIAL_EXT_DTYPE = np.dtype([("emissive", "<f4", 3), ("transmission", "<f4"), ("ior", "<f4"), ("mr_texture", "<u4"), ("_pad", "<u4", 2)])
+MATERIAL_EXT_DTYPE = np.dtype([("emissive", "<f4", 3), ("transmission", "<f4"), ("ior", "<f4"), ("mr_texture", "<u4"),
+                               ("normal_texture", "<u4"), ("emissive_texture", "<u4")])
 assert MATERIAL_EXT_DTYPE.itemsize == 32
 assert VERTEX_DTYPE.itemsize == 48 and MATERIAL_DTYPE.itemsize == 32
 assert OFFSETS_DTYPE.itemsize == 24 and INSTANCE_DTYPE.itemsize == 76
@@ -279,6 +280,11 @@ class IngestedScene:
             uri = doc["images"][doc["textures"][mrt["index"]]["source"]]["uri"]
             if os.path.exists(os.path.join(base, uri)):     # optional: without the file the factors stand alone
                 ext["mr_texture"] = self._texture_from_gltf(doc, mrt, base, decode_image, srgb=False) + 1
+        if mat_idx is not None and not self.ref_quirks:      # build extensions (lit integrator), both optional like the one above
+            for key, field, srgb in (("normalTexture", "normal_texture", False), ("emissiveTexture", "emissive_texture", True)):
+                t = doc["materials"][mat_idx].get(key)
+                if t is not None and os.path.exists(os.path.join(base, doc["images"][doc["textures"][t["index"]]["source"]]["uri"])):
+                    ext[field] = self._texture_from_gltf(doc, t, base, decode_image, srgb=srgb) + 1
         return self.add_material(m, ext)
 
     def instances(self, xform_fn):

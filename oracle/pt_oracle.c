@@ -189,7 +189,7 @@ typedef struct { v3 a, b, c; uint32_t instance, prim; } wtri;
 typedef struct { float lo[3], hi[3]; uint32_t left_first, count; } bnode;   /* count==0: inner, children left_first, left_first+1 */
 
 /* lit integrator: one emissive triangle of the light table */
-typedef struct { v3 a, b, c, n, le; float cdf, pdf_area; } light_t;
+typedef struct { v3 a, b, c, n, le; float cdf, pdf_area; float uv[3][2]; uint32_t etex; /* emissive texture + 1 */ } light_t;
 
 struct orc_scene {
     orc_scene_desc d;
@@ -426,7 +426,7 @@ static inline v3 normal_to_world(const float c[9], v3 n)
                    (c[6] * n.x + c[7] * n.y) + c[8] * n.z);
 }
 
-static const orc_material_ext g_no_ext = { { 0.0f, 0.0f, 0.0f }, 0.0f, 1.5f, 0, { 0, 0 } };
+static const orc_material_ext g_no_ext = { { 0.0f, 0.0f, 0.0f }, 0.0f, 1.5f, 0, 0, 0 };
 static inline const orc_material_ext *material_ext(const orc_scene *s, uint32_t m)
 {
     return s->d.material_ext ? &s->d.material_ext[m] : &g_no_ext;
@@ -479,6 +479,14 @@ static void build_lights(orc_scene *s)
             l->a = t->a; l->b = t->b; l->c = t->c;
             l->n = v3_scale(cr, 1.0f / len);
             l->le = v3_make(e->emissive[0], e->emissive[1], e->emissive[2]);
+            l->etex = e->emissive_texture;
+            {
+                uint64_t ib = (uint64_t)in->off.index_offset + (uint64_t)p * 3;
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    const orc_vertex *vx = &s->d.vertices[in->off.vertex_offset + s->d.indices[ib + c3]];
+                    l->uv[c3][0] = vx->uv[0]; l->uv[c3][1] = vx->uv[1];
+                }
+            }
             l->cdf = (float)(run / total);
             l->pdf_area = (float)((double)power / total) / area;
         }
@@ -953,13 +961,43 @@ static void raygen_pixel_lit(job_t *j, uint32_t x, uint32_t y)
                 albedo = v3_mul(sample_texture(&d->textures[m->base_texture_indice], tu, tv), albedo);
                 j->st.textured_hits++;
             }
+            if (e->normal_texture) {
+                /* glTF normalTexture: tangent-space normal, +Y up.  The vertex format (shared.glsl:1-9) has no tangent, so
+                 * the frame comes from the triangle: T along dP/du, B along -dP/dv (glTF's v runs downwards), both made
+                 * orthogonal to the shading normal.  A degenerate uv mapping, or a perturbed normal that ends up below
+                 * the geometric surface, leaves the shading normal as it is. */
+                v3 tn = sample_texture(&d->textures[e->normal_texture - 1], tu, tv);
+                float mx = tn.x * 2.0f - 1.0f, my = tn.y * 2.0f - 1.0f, mz = tn.z * 2.0f - 1.0f;
+                v3 e1 = v3_sub(wt->b, wt->a), e2 = v3_sub(wt->c, wt->a);
+                float du1 = v1->uv[0] - v0->uv[0], dv1 = v1->uv[1] - v0->uv[1];
+                float du2 = v2->uv[0] - v0->uv[0], dv2 = v2->uv[1] - v0->uv[1];
+                float det = du1 * dv2 - du2 * dv1;
+                float sg = det < 0.0f ? -1.0f : 1.0f;
+                v3 tt = v3_scale(v3_sub(v3_scale(e1, dv2), v3_scale(e2, dv1)), sg);        /* dP/du x |det| */
+                v3 bt = v3_scale(v3_sub(v3_scale(e1, du2), v3_scale(e2, du1)), sg);        /* -dP/dv x |det| */
+                tt = v3_sub(tt, v3_scale(ns, v3_dot(ns, tt)));
+                float tl2 = v3_dot(tt, tt);
+                if (det != 0.0f && tl2 > 0.0f && isfinite(tl2)) {
+                    tt = v3_scale(tt, 1.0f / sqrtf(tl2));
+                    v3 bb = v3_cross(ns, tt);
+                    if (v3_dot(bb, bt) < 0.0f) bb = v3_scale(bb, -1.0f);
+                    v3 np = v3_add(v3_add(v3_scale(tt, mx), v3_scale(bb, my)), v3_scale(ns, mz));
+                    float nl2 = v3_dot(np, np);
+                    if (nl2 > 0.0f && isfinite(nl2)) {
+                        np = v3_scale(np, 1.0f / sqrtf(nl2));
+                        if (v3_dot(np, ng) > 0.0f) ns = np;
+                    }
+                }
+            }
             v3 wo = v3_scale(dir, -1.0f);
             v3 up_o = v3_add(P, v3_scale(ng, p->normal_eps));
             gb_normal = ns;
             gb_dist = v3_length(v3_sub(up_o, o));
 
             if (e->emissive[0] > 0.0f || e->emissive[1] > 0.0f || e->emissive[2] > 0.0f) {
-                v3 le = v3_mul(thr, v3_make(e->emissive[0], e->emissive[1], e->emissive[2]));
+                v3 em = v3_make(e->emissive[0], e->emissive[1], e->emissive[2]);
+                if (e->emissive_texture) em = v3_mul(em, sample_texture(&d->textures[e->emissive_texture - 1], tu, tv));
+                v3 le = v3_mul(thr, em);
                 if (!(prev_pdf > 0.0f)) {
                     L = v3_add(L, le);
                 } else if (s->n_lights) {
@@ -1039,7 +1077,13 @@ static void raygen_pixel_lit(job_t *j, uint32_t x, uint32_t y)
                         float cos_s = v3_dot(ns, wl);
                         float gterm = (cos_s * cos_l) / (dist2 * l->pdf_area);
                         float p_l = (l->pdf_area * dist2) / cos_l;
-                        v3 c = v3_scale(v3_scale(v3_mul(v3_mul(thr, f), l->le), gterm), (p->flags & 2u) ? 1.0f : lit_mis_weight(p_l, p_b));
+                        v3 le_l = l->le;
+                        if (l->etex) {
+                            float lu = (l->uv[0][0] * w0 + l->uv[1][0] * w1) + l->uv[2][0] * w2;
+                            float lv = (l->uv[0][1] * w0 + l->uv[1][1] * w1) + l->uv[2][1] * w2;
+                            le_l = v3_mul(le_l, sample_texture(&d->textures[l->etex - 1], lu, lv));
+                        }
+                        v3 c = v3_scale(v3_scale(v3_mul(v3_mul(thr, f), le_l), gterm), (p->flags & 2u) ? 1.0f : lit_mis_weight(p_l, p_b));
                         hit_rec sh;
                         j->st.shadow_rays++;
                         if (!trace(s, up_o, dl, p->t_min, LIT_SHADOW_TMAX, p->flags, &sh, &j->st))

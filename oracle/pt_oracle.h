@@ -86,7 +86,11 @@ typedef struct {
     float ior;              /* KHR_materials_ior (1.5) */
     uint32_t mr_texture;    /* glTF metallicRoughnessTexture: texture index + 1, 0 = none; G scales the roughness factor,
                                B the metallic factor (lit integrator) */
-    uint32_t _pad[2];
+    uint32_t normal_texture;   /* glTF normalTexture: texture index + 1, 0 = none; a LINEAR texture holding a tangent-space normal
+                                  (x, y, z) = texel * 2 - 1, +Y up; the tangent frame is derived per triangle from its world-space
+                                  positions and uvs (lit integrator; normalTexture.scale is taken as 1) */
+    uint32_t emissive_texture; /* glTF emissiveTexture: texture index + 1, 0 = none; emitted radiance = emissive x texel (lit
+                                  integrator); the light table still picks triangles by area x luminance(emissive) */
 } orc_material_ext;
 
 /* scene options (orc_scene_desc.options); 0 = the reference's behaviour, quirks included */

@@ -39,7 +39,8 @@ MATERIAL_DTYPE = np.dtype([("base_color", "<f4", 4), ("has_base_texture", "<u4")
 OFFSETS_DTYPE = np.dtype([("vertex_offset", "<u4"), ("vertex_count", "<u4"), ("material_offset", "<u4"),
                           ("padding", "<u4"), ("index_offset", "<u4"), ("index_count", "<u4")])
 INSTANCE_DTYPE = np.dtype([("xform", "<f4", (3, 4)), ("geometry", "<u4"), ("off", OFFSETS_DTYPE)])
-MATERIAL_EXT_DTYPE = np.dtype([("emissive", "<f4", 3), ("transmission", "<f4"), ("ior", "<f4"), ("mr_texture", "<u4"), ("_pad", "<u4", 2)])
+MATERIAL_EXT_DTYPE = np.dtype([("emissive", "<f4", 3), ("transmission", "<f4"), ("ior", "<f4"), ("mr_texture", "<u4"),
+                               ("normal_texture", "<u4"), ("emissive_texture", "<u4")])
 
 
 class Camera(C.Structure):

@@ -520,8 +520,11 @@ int ptx_set_material_ext(ptx_context *c, uint32_t index, const ptx_material_ext 
         return fail(c, PTX_ERR_INVALID, "ptx_set_material_ext: mr_texture names a texture that has not been added");
     if (ext->mr_texture && (c->textures[ext->mr_texture - 1].srgb & PTX_TEXTURE_SRGB))
         return fail(c, PTX_ERR_INVALID, "ptx_set_material_ext: mr_texture must be a linear (non-sRGB) texture");
+    if (ext->normal_texture > c->textures.size() || ext->emissive_texture > c->textures.size())
+        return fail(c, PTX_ERR_INVALID, "ptx_set_material_ext: normal_texture / emissive_texture names a texture that has not been added");
+    if (ext->normal_texture && (c->textures[ext->normal_texture - 1].srgb & PTX_TEXTURE_SRGB))
+        return fail(c, PTX_ERR_INVALID, "ptx_set_material_ext: normal_texture must be a linear (non-sRGB) texture");
     c->material_ext[index] = *ext;
-    c->material_ext[index]._pad[0] = c->material_ext[index]._pad[1] = 0;
     c->materials_dirty = true;
     return PTX_OK;
 }
@@ -780,6 +783,13 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
             l.n[0] = cr[0] * il; l.n[1] = cr[1] * il; l.n[2] = cr[2] * il;
             l.le_r = e.emissive[0]; l.le_g = e.emissive[1]; l.le_b = e.emissive[2];
             l.pdf_area = 0.0f;
+            {
+                const Geometry &g = c->geometries[inst[tri_inst[t]].geometry];
+                const uint32_t *ix = &c->indices[g.first_index + (uint64_t)tri_prim[t] * 3];
+                memcpy(l.uv0, c->vertices[g.first_vertex + ix[0]].uv, 8); memcpy(l.uv1, c->vertices[g.first_vertex + ix[1]].uv, 8);
+                memcpy(l.uv2, c->vertices[g.first_vertex + ix[2]].uv, 8);
+                l.etex = e.emissive_texture; l._pad = 0;
+            }
             lights.push_back(l); power.push_back(pw); area.push_back(ar);
         }
         if (!(total > 0.0)) lights.clear();
@@ -807,6 +817,7 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
         lm.metallic = c->materials[i].metallic;
         lm.transmission = c->material_ext[i].transmission; lm.ior = c->material_ext[i].ior;
         lm.mr_texture = c->material_ext[i].mr_texture;
+        lm.normal_texture = c->material_ext[i].normal_texture; lm.emissive_texture = c->material_ext[i].emissive_texture;
     }
 
     lap("lights");

@@ -58,15 +58,19 @@ struct alignas(16) LitMaterial {
     float transmission, ior;
     float pdf_area;      // light pick density per area for a point on a triangle of this material (luminance / total power)
     uint32_t mr_texture; // metallic-roughness texture index + 1, 0 = none
+    uint32_t normal_texture, emissive_texture;   // index + 1, 0 = none (ptx_material_ext)
+    uint32_t _pad[2];
 };
-static_assert(sizeof(LitMaterial) == 32, "LitMaterial must be 32 bytes");
+static_assert(sizeof(LitMaterial) == 48, "LitMaterial must be 48 bytes");
 struct alignas(16) LightRec {          // one emissive triangle, world space
     float a[3]; float pdf_area;        // pick probability / area
     float b[3]; float le_r;
     float c[3]; float le_g;
     float n[3]; float le_b;
+    float uv0[2], uv1[2];              // the triangle's texture coordinates and its material's emissive texture (index + 1,
+    float uv2[2]; uint32_t etex, _pad; // 0 = none): the radiance of a light sample is le x texel at the sampled point
 };
-static_assert(sizeof(LightRec) == 64, "LightRec must be 64 bytes");
+static_assert(sizeof(LightRec) == 96, "LightRec must be 96 bytes");
 
 struct TexDesc {
     const uint8_t *texels;   // RGBA8, row 0 first

@@ -894,6 +894,33 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
                 f3 tx = tex < kLdsTextures ? sample_texture(s_tex[tex], s_lut, tu, tv) : sample_texture(sc.textures[tex], s_lut, tu, tv);
                 albedo = tx * albedo;
             }
+            if (lm.normal_texture) {
+                // glTF normalTexture (oracle: raygen_pixel_lit): tangent-space normal, +Y up, the frame derived from the
+                // triangle -- T along dP/du, B along -dP/dv, both made orthogonal to the shading normal; a degenerate uv
+                // mapping or a perturbed normal below the geometric surface leaves the shading normal as it is
+                const uint32_t nt = lm.normal_texture - 1u;
+                const f3 tn = nt < kLdsTextures ? sample_texture(s_tex[nt], s_lut, tu, tv) : sample_texture(sc.textures[nt], s_lut, tu, tv);
+                const float mx = tn.x * 2.0f - 1.0f, my = tn.y * 2.0f - 1.0f, mz = tn.z * 2.0f - 1.0f;
+                const f3 e1 = vb - va, e2 = vc - va;
+                const float du1 = s2.w - s2.y, dv1 = s3.x - s2.z, du2 = s3.y - s2.y, dv2 = s3.z - s2.z;
+                const float det = du1 * dv2 - du2 * dv1;
+                const float sg = det < 0.0f ? -1.0f : 1.0f;
+                f3 tt = (e1 * dv2 - e2 * dv1) * sg;
+                const f3 bt = (e1 * du2 - e2 * du1) * sg;
+                tt = tt - ns * dot(ns, tt);
+                const float tl2 = dot(tt, tt);
+                if (det != 0.0f && tl2 > 0.0f && isfinite(tl2)) {
+                    tt = tt * (1.0f / sqrtf(tl2));
+                    f3 bb = cross(ns, tt);
+                    if (dot(bb, bt) < 0.0f) bb = bb * -1.0f;
+                    f3 np = (tt * mx + bb * my) + ns * mz;
+                    const float nl2 = dot(np, np);
+                    if (nl2 > 0.0f && isfinite(nl2)) {
+                        np = np * (1.0f / sqrtf(nl2));
+                        if (dot(np, ng) > 0.0f) ns = np;
+                    }
+                }
+            }
             const f3 wo = dir * -1.0f;
             const f3 up_o = P + ng * f.normal_eps;
             gb_normal = ns;
@@ -901,7 +928,12 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
             if (depth == 0 && sample == f.ids_sample) { id_inst = __float_as_uint(s4.y); id_prim = __float_as_uint(s4.z); }
 
             if (lm.emissive[0] > 0.0f || lm.emissive[1] > 0.0f || lm.emissive[2] > 0.0f) {
-                const f3 le = thr * mk3(lm.emissive[0], lm.emissive[1], lm.emissive[2]);
+                f3 em = mk3(lm.emissive[0], lm.emissive[1], lm.emissive[2]);
+                if (lm.emissive_texture) {
+                    const uint32_t et = lm.emissive_texture - 1u;
+                    em = em * (et < kLdsTextures ? sample_texture(s_tex[et], s_lut, tu, tv) : sample_texture(sc.textures[et], s_lut, tu, tv));
+                }
+                const f3 le = thr * em;
                 if (!(prev_pdf > 0.0f)) {
                     add = le;
                     have_add = true;
@@ -983,7 +1015,16 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
                         const float cos_s = dot(ns, wl);
                         const float gterm = (cos_s * cos_l) / (dist2 * l0.w);
                         const float p_l = (l0.w * dist2) / cos_l;
-                        const f3 c = (((thr * fb) * mk3(l1.w, l2.w, l3.w)) * gterm) * lit_mis_weight(p_l, p_b);
+                        f3 le_l = mk3(l1.w, l2.w, l3.w);
+                        const float4 l5 = lp[5];
+                        if (__float_as_uint(l5.z)) {
+                            const float4 l4 = lp[4];
+                            const uint32_t et = __float_as_uint(l5.z) - 1u;
+                            const float lu = (l4.x * w0 + l4.z * w1) + l5.x * w2;
+                            const float lv = (l4.y * w0 + l4.w * w1) + l5.y * w2;
+                            le_l = le_l * (et < kLdsTextures ? sample_texture(s_tex[et], s_lut, lu, lv) : sample_texture(sc.textures[et], s_lut, lu, lv));
+                        }
+                        const f3 c = (((thr * fb) * le_l) * gterm) * lit_mis_weight(p_l, p_b);
                         want_shadow = true;
                         q0 = make_float4(up_o.x, up_o.y, up_o.z, r0.w);
                         q1 = make_float4(dl.x, dl.y, dl.z, 0.0f);

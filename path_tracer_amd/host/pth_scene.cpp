@@ -169,6 +169,21 @@ Material material_from_gltf(const Json &doc, const Json *gltf_mat, Renderer &ren
                 }
             }
     }
+    if (gltf_mat && !renderer.ref_quirks()) {
+        // build extensions (lit integrator), optional like the one above: tangent-space normal map (linear) and emissive
+        // map (sRGB); the reference reads neither
+        struct { const char *key; uint32_t *field; bool srgb; } maps[2] = {{"normalTexture", &m.normal_texture, false},
+                                                                           {"emissiveTexture", &m.emissive_texture, true}};
+        for (auto &mp : maps)
+            if (const Json *t = gltf_mat->find(mp.key)) {
+                const Json &image = doc.at("images").at((size_t)doc.at("textures").at((size_t)t->get_int("index", 0)).get_int("source", 0));
+                std::string path = gltf_dir + "/" + image.get_string("uri", "");
+                if (FILE *probe = fopen(path.c_str(), "rb")) {
+                    fclose(probe);
+                    *mp.field = texture_from_gltf(doc, *t, renderer, gltf_dir, mp.srgb).bindless_indice + 1u;
+                }
+            }
+    }
     if (gltf_mat) {
         // build extension: emission / transmission / ior (ignored by the reference and by its integrator)
         float strength = 1.0f;
@@ -188,7 +203,7 @@ Material material_from_gltf(const Json &doc, const Json *gltf_mat, Renderer &ren
     m.shared_buffer_index = renderer.scene.add_material(sm);
     ptx_material_ext ext; memset(&ext, 0, sizeof ext);
     memcpy(ext.emissive, m.emissive, 12); ext.transmission = m.transmission; ext.ior = m.ior;
-    ext.mr_texture = m.mr_texture;
+    ext.mr_texture = m.mr_texture; ext.normal_texture = m.normal_texture; ext.emissive_texture = m.emissive_texture;
     renderer.scene.set_material_ext(m.shared_buffer_index, ext);
     return m;
 }

@@ -52,6 +52,8 @@ struct Material {
     float transmission = 0.0f;          // KHR_materials_transmission
     float ior = 1.5f;                   // KHR_materials_ior
     uint32_t mr_texture = 0;            // metallicRoughnessTexture: bindless index + 1, 0 = none (not under ref quirks)
+    uint32_t normal_texture = 0;        // normalTexture (linear), emissiveTexture (sRGB): the same convention
+    uint32_t emissive_texture = 0;
     uint64_t get_shared_buffer_offset() const { return shared_buffer_index; }
 };
 

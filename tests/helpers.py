@@ -145,10 +145,11 @@ def rel_mse(a, b, eps=1e-2):
     return float(np.mean((a - b) ** 2 / (b * b + eps)))
 
 
-def write_mr_quad_gltf(dirpath):
+def write_mr_quad_gltf(dirpath, with_maps=False):
     """A lit test scene written from scratch: a 4 x 4 m floor quad with uv in [0, 2] carrying a base-colour texture
     and a metallicRoughnessTexture (procedural PNGs, G = roughness, B = metallic), under a small emissive quad.
-    Returns the .gltf path."""
+    with_maps: the floor also names a normalTexture (a field of bumps, tangent space, +Y up) and the lamp an
+    emissiveTexture (a striped sRGB image).  Returns the .gltf path."""
     import json
     import struct
     from PIL import Image
@@ -160,6 +161,15 @@ def write_mr_quad_gltf(dirpath):
     mr[..., 0] = rng.integers(0, 256, (32, 32))                            # occlusion channel: unused
     Image.fromarray(mr).save(os.path.join(dirpath, "mr.png"))
     Image.fromarray(rng.integers(60, 256, (16, 16, 3), dtype=np.uint8)).save(os.path.join(dirpath, "base.png"))
+    if with_maps:
+        gy, gx = np.mgrid[0:64, 0:64].astype(np.float64)
+        hx, hy = 0.7 * np.cos(gx * (2 * np.pi / 16)), 0.7 * np.sin(gy * (2 * np.pi / 8))      # slopes of a bumpy height field
+        n = np.stack([-hx, -hy, np.ones_like(hx)], -1)
+        n /= np.linalg.norm(n, axis=-1, keepdims=True)
+        Image.fromarray(np.uint8(np.round((n * 0.5 + 0.5) * 255))).save(os.path.join(dirpath, "normal.png"))
+        em = np.zeros((8, 8, 3), np.uint8)
+        em[:, ::2] = (255, 255, 255); em[:, 1::2] = (40, 90, 200)
+        Image.fromarray(em).save(os.path.join(dirpath, "emit.png"))
 
     def quad(y, half, flip):
         p = [[-half, y, -half], [half, y, -half], [half, y, half], [-half, y, half]]
@@ -194,6 +204,11 @@ def write_mr_quad_gltf(dirpath):
            "samplers": [{"magFilter": 9729, "wrapS": 10497, "wrapT": 10497}, {"magFilter": 9728, "wrapS": 33071, "wrapT": 33071}],
            "images": [{"uri": "base.png"}, {"uri": "mr.png"}],
            "buffers": [{"uri": "mrquad.bin", "byteLength": len(blob)}], "bufferViews": views, "accessors": accessors}
+    if with_maps:
+        doc["materials"][0]["normalTexture"] = {"index": 2}
+        doc["materials"][1]["emissiveTexture"] = {"index": 3}
+        doc["textures"] += [{"source": 2, "sampler": 0}, {"source": 3, "sampler": 1}]
+        doc["images"] += [{"uri": "normal.png"}, {"uri": "emit.png"}]
     path = os.path.join(dirpath, "mrquad.gltf")
     json.dump(doc, open(path, "w"))
     return path

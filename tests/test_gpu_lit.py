@@ -138,6 +138,12 @@ def test_lit_stress_scene_many_lights(oracle, gpu_ctx_factory):
         if i % 3 == 0:
             # a metallic-roughness map from the linear (even-numbered) textures, beyond the 64 descriptors kept in LDS too
             ing.material_ext[i]["mr_texture"] = (2 * i) % 70 + 1
+        if i % 2 == 1:
+            # tangent-space normal maps (random texels: perturbed normals above and below the surface, confetti with
+            # random uvs: degenerate and mirrored tangent frames), again from the linear textures
+            ing.material_ext[i]["normal_texture"] = (2 * i + 4) % 70 + 1
+        if i % 14 == 0:
+            ing.material_ext[i]["emissive_texture"] = (3 * i + 1) % 70 + 1      # emitters with an emissive map (hits and light samples)
     ctx = gpu_ctx_factory()
     upload(ctx, ing, oracle, options=capi.SCENE_WORLD_NORMALS, with_material_ext=True)
     sc = oracle.scene_from_ingest(ing, options=oracle.SCENE_WORLD_NORMALS, with_material_ext=True)
@@ -296,4 +302,47 @@ def test_material_sort_option_changes_nothing_but_the_order(oracle, monkeypatch)
     want_ref = sc.render(cam, 200, 136, 2, SEED)
     got_ref = gpu_render(ctx, oracle, cam, 200, 136, 2)
     assert_images_bit_equal(got_ref, want_ref, "reference integrator, material sort env set")
+    ctx.close()
+
+
+def test_host_normal_and_emissive_textures(oracle, tmp_path):
+    """normalTexture / emissiveTexture through the C++ host's glTF import against the oracle-side ingest of the same
+    file (lit integrator): same bindless indices, bit-identical images; and the C ABI's checks on the new fields."""
+    from helpers import write_mr_quad_gltf
+    from oracle.gltf_ingest import IngestedScene
+    from path_tracer_amd import capi, host
+    path = write_mr_quad_gltf(str(tmp_path), with_maps=True)
+    r = host.Renderer(96, 96, 0)
+    r.set_ref_quirks(False)
+    r.import_gltf(path)
+    fov = np.deg2rad(np.float32(55.0))
+    r.set_camera([0.0, 1.2, 3.5], host.yaw_quat(0.0), fov, 0.1, 1000.0)
+    r.set_seed(SEED, fixed=True)
+    r.set_params(capi.default_params(max_depth=6, integrator=capi.INTEGRATOR_LIT))
+    r.record_commands(); r.record_commands()
+    r.record_commands_batch(4)
+    got = {k: r.read_image(v) for k, v in (("albedo", capi.IMAGE_ALBEDO), ("normal", capi.IMAGE_NORMAL),
+                                           ("depth", capi.IMAGE_DEPTH), ("ids", capi.IMAGE_PRIMARY_ID))}
+    ing = IngestedScene(ref_quirks=False)
+    ing.import_gltf(path)
+    assert ing.material_ext["normal_texture"].tolist() == [3, 0] and ing.material_ext["emissive_texture"].tolist() == [0, 4]
+    sc = oracle.scene_from_ingest(ing, options=oracle.SCENE_WORLD_NORMALS | oracle.SCENE_TEXTURE_TIMES_FACTOR, with_material_ext=True)
+    cam = oracle.camera_matrices([0.0, 1.2, 3.5], oracle.yaw_quat(0), fov, 1.0, 0.1, 1000.0)
+    want = sc.render(cam, 96, 96, 4, SEED, params=oracle.default_params(max_depth=6, integrator=oracle.INTEGRATOR_LIT))
+    assert_images_bit_equal(got, want, "host normal + emissive maps")
+    floor = want["ids"][..., 0] == 0
+    assert np.abs(want["normal"][floor][:, :3] - np.float32([0, 1, 0])).max() > 0.2      # the bumps reach the G-buffer normal
+    r.close()
+    ctx = capi.Context(0)
+    ctx.add_material(np.zeros(1, dtype=capi.MATERIAL_DTYPE))
+    for field in ("normal_texture", "emissive_texture"):
+        e = np.zeros(1, dtype=capi.MATERIAL_EXT_DTYPE); e["ior"] = 1.5; e[field] = 1
+        with pytest.raises(capi.PtxError):
+            ctx.set_material_ext(0, e)                   # no such texture yet
+    ctx.add_texture(np.zeros((2, 2, 4), np.uint8), capi.TEXTURE_SRGB)
+    e = np.zeros(1, dtype=capi.MATERIAL_EXT_DTYPE); e["ior"] = 1.5; e["normal_texture"] = 1
+    with pytest.raises(capi.PtxError):
+        ctx.set_material_ext(0, e)                       # a normal map must be linear
+    e["normal_texture"] = 0; e["emissive_texture"] = 1
+    ctx.set_material_ext(0, e)                           # an emissive map may be sRGB
     ctx.close()

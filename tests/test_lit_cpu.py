@@ -282,3 +282,54 @@ def test_metallic_roughness_texture_ingest_and_effect(oracle, tmp_path):
     gone = IngestedScene(ref_quirks=False)
     gone.import_gltf(path)
     assert gone.material_ext["mr_texture"].tolist() == [0, 0] and len(gone.textures) == 1
+
+
+def test_normal_and_emissive_textures_ingest_and_effect(oracle, tmp_path):
+    """glTF normalTexture / emissiveTexture (ptx_material_ext.normal_texture / .emissive_texture): read only without the
+    reference's quirks -- the normal map as a linear texture, the emissive map as sRGB --, optional when the file is
+    absent.  A white emissive map is the same image bit for bit as none (hits on the emitter AND light samples go
+    through the texture); a striped one darkens the scene; a normal map changes the shading, not the geometry."""
+    from helpers import write_mr_quad_gltf
+    from oracle.gltf_ingest import IngestedScene
+    from PIL import Image
+    path = write_mr_quad_gltf(str(tmp_path), with_maps=True)
+    ref = IngestedScene()
+    ref.import_gltf(path)
+    assert ref.material_ext["normal_texture"].tolist() == [0, 0] and ref.material_ext["emissive_texture"].tolist() == [0, 0]
+    ing = IngestedScene(ref_quirks=False)
+    ing.import_gltf(path)
+    assert ing.material_ext["mr_texture"].tolist() == [2, 0]
+    assert ing.material_ext["normal_texture"].tolist() == [3, 0] and ing.material_ext["emissive_texture"].tolist() == [0, 4]
+    assert [f for _, f in ing.textures] == [1 | 2 | 4, 0, 2 | 4, 1]     # normal: UNORM with the floor's sampler; emissive: sRGB, clamp, nearest
+    cam = oracle.camera_matrices([0, 1.2, 3.5], oracle.yaw_quat(0), np.deg2rad(np.float32(55)), 1.0, 0.1, 1000.0)
+    P = oracle.default_params(max_depth=4, integrator=oracle.INTEGRATOR_LIT)
+    opts = oracle.SCENE_WORLD_NORMALS | oracle.SCENE_TEXTURE_TIMES_FACTOR
+
+    def render(ingested, spp=16):
+        return oracle.scene_from_ingest(ingested, options=opts, with_material_ext=True).render(cam, 48, 48, spp, SEED, params=P)
+    full = render(ing)
+    assert np.isfinite(full["albedo"]).all()
+    # normal map off: same first hits and depth, another shading normal and another image
+    ing.material_ext["normal_texture"][0] = 0
+    flat = render(ing)
+    assert np.array_equal(flat["ids"], full["ids"]) and np.array_equal(flat["depth"], full["depth"])
+    floor = full["ids"][..., 0] == 0
+    assert np.abs(flat["normal"][floor][:, :3] - full["normal"][floor][:, :3]).max() > 0.2
+    assert np.allclose(np.linalg.norm(full["normal"][floor][:, :3], axis=1), 1.0, atol=1e-5)
+    assert np.allclose(flat["normal"][floor][:, :3], [0, 1, 0])
+    assert np.abs(flat["albedo"] - full["albedo"]).mean() > 1e-3
+    # emissive map: white == none, stripes emit less
+    striped = flat["albedo"]
+    ing.material_ext["emissive_texture"][1] = 0
+    none = render(ing)["albedo"]
+    ing.textures[3] = (np.full((8, 8, 4), 255, np.uint8), ing.textures[3][1])
+    ing.material_ext["emissive_texture"][1] = 4
+    white = render(ing)["albedo"]
+    assert np.array_equal(white.view(np.uint32), none.view(np.uint32))
+    assert striped[..., :3].mean() < 0.95 * none[..., :3].mean()
+    for f in ("normal.png", "emit.png"):
+        os.remove(os.path.join(str(tmp_path), f))
+    gone = IngestedScene(ref_quirks=False)
+    gone.import_gltf(path)
+    assert gone.material_ext["normal_texture"].tolist() == [0, 0] and gone.material_ext["emissive_texture"].tolist() == [0, 0]
+    assert len(gone.textures) == 2
