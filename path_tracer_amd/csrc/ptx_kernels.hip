@@ -524,27 +524,45 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
         for (uint32_t w = threadIdx.x; w < nw; w += kShadeBlock)
             reinterpret_cast<uint32_t *>(s_tex)[w] = reinterpret_cast<const uint32_t *>(sc.textures)[w];
     }
-    for (uint32_t tile = blockIdx.x; (uint64_t)tile * kShadeBlock < n_live; tile += gridDim.x) {
-    // Every fetch that does not depend on another is issued before the first wait: the ray and its
-    // hit together, then the triangle's record.
-    const uint32_t i = tile * kShadeBlock + threadIdx.x;
-    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
-    float2 hr = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
-    if (i < capacity) {
-        r1 = rays_in.dir[i];
-        // camera rays: origin, path index (= queue index) and unit throughput (rgen.glsl:62) are never stored
-        r0 = depth == 0 ? make_float4(f.cam_origin[0], f.cam_origin[1], f.cam_origin[2], __uint_as_float(i)) : rays_in.org[i];
-        r2 = depth == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : rays_in.thr[i];
-        hr = *reinterpret_cast<const float2 *>(hits + i);
+    // The tile loop is software-pipelined.  A tile costs three dependent memory round trips -- ray + hit, the
+    // triangle's record (its index comes with the hit), the block's queue-tail atomic -- and the stage spends 71 % of
+    // its wave time waiting for them (profiles/valu.json).  So the NEXT tile's ray + hit are fetched before this tile
+    // is shaded, and its record is fetched behind this tile's atomic, before anybody waits for that: per tile one
+    // round trip and the arithmetic remain on the critical path.
+    const float4 kZero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    auto fetch_ray = [&](uint32_t tile_, float4 &a0, float4 &a1, float4 &a2, float2 &h) {
+        const uint32_t i_ = tile_ * kShadeBlock + threadIdx.x;
+        a0 = kZero4; a1 = kZero4; a2 = kZero4; h = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
+        if ((uint64_t)tile_ * kShadeBlock < n_live && i_ < capacity) {
+            a1 = rays_in.dir[i_];
+            // camera rays: origin, path index (= queue index) and unit throughput (rgen.glsl:62) are never stored
+            a0 = depth == 0 ? make_float4(f.cam_origin[0], f.cam_origin[1], f.cam_origin[2], __uint_as_float(i_)) : rays_in.org[i_];
+            a2 = depth == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : rays_in.thr[i_];
+            h = *reinterpret_cast<const float2 *>(hits + i_);
+        }
+    };
+    auto tri_of = [&](uint32_t tile_, const float2 &h) -> uint32_t {
+        const uint32_t i_ = tile_ * kShadeBlock + threadIdx.x;
+        return (i_ < capacity && i_ < n_live) ? __float_as_uint(h.y) : 0xFFFFFFFFu;
+    };
+    float4 r0, r1, r2; float2 hr;
+    fetch_ray(blockIdx.x, r0, r1, r2, hr);
+    float4 t0 = kZero4, t1 = kZero4, t2 = kZero4, s0 = kZero4, s1 = kZero4, s2 = kZero4, s3 = kZero4, s4 = kZero4;
+    {
+        const uint32_t tri0 = tri_of(blockIdx.x, hr);
+        if (tri0 != 0xFFFFFFFFu) {
+            const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri0);
+            t0 = sp[0]; t1 = sp[1]; t2 = sp[2]; s0 = sp[3]; s1 = sp[4]; s2 = sp[5]; s3 = sp[6]; s4 = sp[7];
+        }
     }
+    __syncthreads();      // the tables are in LDS
+    for (uint32_t tile = blockIdx.x; (uint64_t)tile * kShadeBlock < n_live; tile += gridDim.x) {
+    const uint32_t i = tile * kShadeBlock + threadIdx.x;
     const bool valid = i < capacity && i < n_live;
     const uint32_t tri = valid ? __float_as_uint(hr.y) : 0xFFFFFFFFu;
-    float4 t0 = r0, t1 = r0, t2 = r0, s0 = r0, s1 = r0, s2 = r0, s3 = r0, s4 = r0;
-    if (tri != 0xFFFFFFFFu) {
-        const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri);
-        t0 = sp[0]; t1 = sp[1]; t2 = sp[2]; s0 = sp[3]; s1 = sp[4]; s2 = sp[5]; s3 = sp[6]; s4 = sp[7];
-    }
-    __syncthreads();
+    // the next tile's ray and hit, in flight while this tile is shaded
+    float4 nr0, nr1, nr2; float2 nhr;
+    fetch_ray(tile + gridDim.x, nr0, nr1, nr2, nhr);
 
     bool alive = false, was_hit = false;
     float4 o0, o1, o2;
@@ -653,12 +671,22 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(SceneDev sc, FrameDev f, 
         }
         if (lane == 0 && h) atomicAdd(&counters[kHitCounter], h);
     }
+    // the next tile's record: its fetch goes out behind the atomic, before the barrier that waits for the atomic's result
+    {
+        const uint32_t ntri = tri_of(tile + gridDim.x, nhr);
+        t0 = kZero4; t1 = kZero4; t2 = kZero4; s0 = kZero4; s1 = kZero4; s2 = kZero4; s3 = kZero4; s4 = kZero4;
+        if ((uint64_t)(tile + gridDim.x) * kShadeBlock < n_live && ntri != 0xFFFFFFFFu) {
+            const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + ntri);
+            t0 = sp[0]; t1 = sp[1]; t2 = sp[2]; s0 = sp[3]; s1 = sp[4]; s2 = sp[5]; s3 = sp[6]; s4 = sp[7];
+        }
+    }
     __syncthreads();
     if (alive) {
         uint32_t before = wave ? s_wave_live[wave - 1] : 0u;
         uint32_t slot = s_base + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
         rays_out.org[slot] = o0; rays_out.dir[slot] = o1; rays_out.thr[slot] = o2;
     }
+    r0 = nr0; r1 = nr1; r2 = nr2; hr = nhr;
     __syncthreads();      // the LDS scan words are reused by the next tile
     }
 }
