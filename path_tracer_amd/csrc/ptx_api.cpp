@@ -1030,7 +1030,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
         }
         // the bounce from which the fused tail launch takes the chunk to its end (reference integrator, uninstrumented runs)
         uint32_t tail_at = bounces;
-        if (c->tail_rays && !lit && !c->count_traversal && c->have_frac && !c->frac_lit && c->frac_bounces == bounces)
+        if (c->tail_rays && !c->count_traversal && !c->material_sort && c->have_frac && c->frac_lit == lit && c->frac_bounces == bounces)
             for (uint32_t b = 1; b < bounces; ++b)
                 if (1.5 * (double)c->live_frac[b] * (double)n_paths <= (double)std::max<uint64_t>(c->tail_rays, n_paths >> c->tail_shift)) { tail_at = b; break; }
         // Frame-sized chunks (<= 4 Mi paths) with another chunk in flight: half the resident waves each, so that the two
@@ -1048,7 +1048,8 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
             RayQueue shadow_q = make_ray_queue(lit ? ps.d_rays[2] : ps.d_rays[0], ps.capacity);
             uint64_t *trav = c->count_traversal ? c->d_totals + 3 : nullptr;
             if (b == tail_at) {      // (its time shows in total_ms only: extend_ms / shade_ms keep meaning the two kernels)
-                launch_tail(st, sc, f, b, rin, ps.d_counters, n_paths, ps.d_results);
+                if (lit) launch_tail_lit(st, sc, f, b, rin, ps.d_counters, n_paths, ps.d_results);
+                else launch_tail(st, sc, f, b, rin, ps.d_counters, n_paths, ps.d_results);
                 c->n_tail_launches++;
                 break;
             }

@@ -147,6 +147,9 @@ uint32_t extend_resident_waves(int device);
 // every remaining bounce of the rays queued for bounce `depth0` (count in counters[depth0]), reference integrator
 void launch_tail(hipStream_t s, const SceneDev &sc, const FrameDev &f, uint32_t depth0, RayQueue rays, uint32_t *counters,
                  uint32_t capacity, float4 *results);
+// the same for the lit integrator (occlusion queries included); depth0 >= 1
+void launch_tail_lit(hipStream_t s, const SceneDev &sc, const FrameDev &f, uint32_t depth0, RayQueue rays, uint32_t *counters,
+                     uint32_t capacity, float4 *results);
 void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
                   RayQueue rays_in, const HitOut *hits, uint32_t *counters, uint32_t capacity, RayQueue rays_out,
                   float4 *results);

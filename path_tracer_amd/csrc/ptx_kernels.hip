@@ -834,6 +834,224 @@ __device__ __forceinline__ uint32_t block_reserve(bool flag, const BlockScan &bs
     return slot;
 }
 
+// One hit of the lit integrator (oracle: raygen_pixel_lit, the `hit` branch): emission, one next-event-estimation sample
+// (its occlusion ray comes back in q0 .. q2), BSDF sampling, Russian roulette.  Shared by the wavefront stage (k_shade_lit)
+// and the fused tail (k_tail_lit): one set of expression trees, so both give the oracle's bits.
+struct LitState {
+    f3 thr, add, gb_normal, new_o, new_d;
+    float gb_dist, next_pdf;
+    bool have_add, done, was_hit, want_shadow;
+    uint32_t id_inst, id_prim;
+    float4 q0, q1, q2;
+};
+__device__ __forceinline__ void lit_shade_hit(const SceneDev &sc, const FrameDev &f, const TexDesc *s_tex, const float *s_lut,
+                                              uint32_t depth, f3 o, f3 dir, uint32_t uv_state, uint32_t rng_acc, float prev_pdf,
+                                              float hit_t, float path_bits, bool want_ids,
+                                              const float4 &t0, const float4 &t1, const float4 &t2, const float4 &s0,
+                                              const float4 &s1, const float4 &s2, const float4 &s3, const float4 &s4, LitState &S)
+{
+    f3 &thr = S.thr, &add = S.add, &gb_normal = S.gb_normal, &new_o = S.new_o, &new_d = S.new_d;
+    float &gb_dist = S.gb_dist, &next_pdf = S.next_pdf;
+    bool &have_add = S.have_add, &done = S.done, &was_hit = S.was_hit, &want_shadow = S.want_shadow;
+    uint32_t &id_inst = S.id_inst, &id_prim = S.id_prim;
+    float4 &q0 = S.q0, &q1 = S.q1, &q2 = S.q2;
+    was_hit = true;
+    const f3 va = mk3(t0.x, t0.y, t0.z), vb = mk3(t1.x, t1.y, t1.z), vc = mk3(t2.x, t2.y, t2.z);
+    float hu, hv;
+    tri_uv(o, dir, va, vb, vc, hu, hv);
+    const float bx = 1.0f - hu - hv, by = hu, bz = hv;
+    const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
+    f3 ns = normalize((n0 * bx + n1 * by) + n2 * bz);
+    f3 ng = normalize(cross(vb - va, vc - va));
+    bool front = true;
+    if (dot(ng, dir) > 0.0f) { ng = ng * -1.0f; front = false; }
+    if (dot(ns, ng) < 0.0f) ns = ns * -1.0f;
+    const float tu = (s2.y * bx + s2.w * by) + s3.y * bz;
+    const float tv = (s2.z * bx + s3.x * by) + s3.z * bz;
+    const f3 P = o + dir * hit_t;
+    const LitMaterial lm = sc.lit_materials[__float_as_uint(s4.w)];
+    f3 albedo = mk3(t2.w, s3.w, s4.x);
+    const uint32_t tex = __float_as_uint(t0.w);
+    if (tex != 0xFFFFFFFFu) {
+        f3 tx = tex < kLdsTextures ? sample_texture(s_tex[tex], s_lut, tu, tv) : sample_texture(sc.textures[tex], s_lut, tu, tv);
+        albedo = tx * albedo;
+    }
+    if (lm.normal_texture) {
+        // glTF normalTexture (oracle: raygen_pixel_lit): tangent-space normal, +Y up, the frame derived from the
+        // triangle -- T along dP/du, B along -dP/dv, both made orthogonal to the shading normal; a degenerate uv
+        // mapping or a perturbed normal below the geometric surface leaves the shading normal as it is
+        const uint32_t nt = lm.normal_texture - 1u;
+        const f3 tn = nt < kLdsTextures ? sample_texture(s_tex[nt], s_lut, tu, tv) : sample_texture(sc.textures[nt], s_lut, tu, tv);
+        const float mx = tn.x * 2.0f - 1.0f, my = tn.y * 2.0f - 1.0f, mz = tn.z * 2.0f - 1.0f;
+        const f3 e1 = vb - va, e2 = vc - va;
+        const float du1 = s2.w - s2.y, dv1 = s3.x - s2.z, du2 = s3.y - s2.y, dv2 = s3.z - s2.z;
+        const float det = du1 * dv2 - du2 * dv1;
+        const float sg = det < 0.0f ? -1.0f : 1.0f;
+        f3 tt = (e1 * dv2 - e2 * dv1) * sg;
+        const f3 bt = (e1 * du2 - e2 * du1) * sg;
+        tt = tt - ns * dot(ns, tt);
+        const float tl2 = dot(tt, tt);
+        if (det != 0.0f && tl2 > 0.0f && isfinite(tl2)) {
+            tt = tt * (1.0f / sqrtf(tl2));
+            f3 bb = cross(ns, tt);
+            if (dot(bb, bt) < 0.0f) bb = bb * -1.0f;
+            f3 np = (tt * mx + bb * my) + ns * mz;
+            const float nl2 = dot(np, np);
+            if (nl2 > 0.0f && isfinite(nl2)) {
+                np = np * (1.0f / sqrtf(nl2));
+                if (dot(np, ng) > 0.0f) ns = np;
+            }
+        }
+    }
+    const f3 wo = dir * -1.0f;
+    const f3 up_o = P + ng * f.normal_eps;
+    gb_normal = ns;
+    gb_dist = length(up_o - o);
+    if (want_ids) { id_inst = __float_as_uint(s4.y); id_prim = __float_as_uint(s4.z); }
+
+    if (lm.emissive[0] > 0.0f || lm.emissive[1] > 0.0f || lm.emissive[2] > 0.0f) {
+        f3 em = mk3(lm.emissive[0], lm.emissive[1], lm.emissive[2]);
+        if (lm.emissive_texture) {
+            const uint32_t et = lm.emissive_texture - 1u;
+            em = em * (et < kLdsTextures ? sample_texture(s_tex[et], s_lut, tu, tv) : sample_texture(sc.textures[et], s_lut, tu, tv));
+        }
+        const f3 le = thr * em;
+        if (!(prev_pdf > 0.0f)) {
+            add = le;
+            have_add = true;
+        } else if (sc.n_lights) {
+            // the light sampling of the previous vertex could have produced this point too
+            const float cos_l = fabsf(dot(ng, dir));
+            const float p_l = (lm.pdf_area * (hit_t * hit_t)) / cos_l;
+            add = le * lit_mis_weight(prev_pdf, p_l);
+            have_add = true;
+        }
+    }
+    const float u_lobe = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedLobe);
+    const float u1 = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedU1);
+    const float u2 = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedU2);
+    if (lm.transmission > 0.0f && u_lobe < lm.transmission) {
+        // smooth dielectric
+        const float ior = lm.ior;
+        const float eta = front ? 1.0f / ior : ior;
+        float cosi = dot(wo, ns);
+        if (cosi < 0.0f) cosi = 0.0f;
+        if (cosi > 1.0f) cosi = 1.0f;
+        const float sin2t = (eta * eta) * (1.0f - cosi * cosi);
+        bool reflect = true;
+        float cost = 0.0f;
+        if (sin2t < 1.0f) {
+            cost = sqrtf(1.0f - sin2t);
+            float r0s = (1.0f - ior) / (1.0f + ior);
+            r0s = r0s * r0s;
+            const float c = front ? cosi : cost;
+            const float fr = r0s + (1.0f - r0s) * pow5(1.0f - c);
+            reflect = u1 < fr;
+        }
+        if (reflect) {
+            new_d = normalize(dir + ns * (2.0f * cosi));
+            new_o = up_o;
+        } else {
+            new_d = normalize(dir * eta + ns * (eta * cosi - cost));
+            new_o = P - ng * f.normal_eps;
+            thr = thr * albedo;
+        }
+        next_pdf = 0.0f;
+    } else {
+        float rough = t1.w, metal = lm.metallic;
+        if (lm.mr_texture) {        // glTF: G = roughness, B = metallic, linear texels, multiplied into the factors
+            const uint32_t mt = lm.mr_texture - 1u;
+            const f3 mr = mt < kLdsTextures ? sample_texture(s_tex[mt], s_lut, tu, tv) : sample_texture(sc.textures[mt], s_lut, tu, tv);
+            rough = rough * mr.y;
+            metal = metal * mr.z;
+        }
+        float alpha = rough * rough;
+        if (alpha < 0.0025f) alpha = 0.0025f;
+        const float a2 = alpha * alpha;
+        const float om = 1.0f - metal;
+        const f3 f0 = mk3(0.04f * om + albedo.x * metal, 0.04f * om + albedo.y * metal, 0.04f * om + albedo.z * metal);
+        const f3 diff = albedo * om;
+        const float p_spec = 0.25f + 0.75f * metal;
+
+        // next-event estimation
+        if (sc.n_lights) {
+            const float ul = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedLight);
+            uint32_t lo = 0, hi = sc.n_lights;
+            while (lo < hi) { uint32_t mid = (lo + hi) / 2u; if (sc.light_cdf[mid] <= ul) lo = mid + 1u; else hi = mid; }
+            if (lo >= sc.n_lights) lo = sc.n_lights - 1u;
+            const float4 *lp = reinterpret_cast<const float4 *>(sc.lights + lo);
+            const float4 l0 = lp[0], l1 = lp[1], l2 = lp[2], l3 = lp[3];
+            const float a = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedLu);
+            const float b = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedLv);
+            const float su = sqrtf(a);
+            const float w0 = 1.0f - su, w1 = su * (1.0f - b), w2 = su * b;
+            const f3 pl = (mk3(l0.x, l0.y, l0.z) * w0 + mk3(l1.x, l1.y, l1.z) * w1) + mk3(l2.x, l2.y, l2.z) * w2;
+            const f3 dl = pl - up_o;
+            const float dist2 = dot(dl, dl);
+            const float inv_dist = 1.0f / sqrtf(dist2);
+            const f3 wl = dl * inv_dist;
+            const float cos_g = dot(ng, wl);
+            const float cos_l = fabsf(dot(mk3(l3.x, l3.y, l3.z), wl));
+            f3 fb; float p_b;
+            if (dist2 > 0.0f && cos_g > 0.0f && cos_l > 0.0f && bsdf_eval(ns, wo, wl, diff, f0, a2, p_spec, fb, p_b)) {
+                const float cos_s = dot(ns, wl);
+                const float gterm = (cos_s * cos_l) / (dist2 * l0.w);
+                const float p_l = (l0.w * dist2) / cos_l;
+                f3 le_l = mk3(l1.w, l2.w, l3.w);
+                const float4 l5 = lp[5];
+                if (__float_as_uint(l5.z)) {
+                    const float4 l4 = lp[4];
+                    const uint32_t et = __float_as_uint(l5.z) - 1u;
+                    const float lu = (l4.x * w0 + l4.z * w1) + l5.x * w2;
+                    const float lv = (l4.y * w0 + l4.w * w1) + l5.y * w2;
+                    le_l = le_l * (et < kLdsTextures ? sample_texture(s_tex[et], s_lut, lu, lv) : sample_texture(sc.textures[et], s_lut, lu, lv));
+                }
+                const f3 c = (((thr * fb) * le_l) * gterm) * lit_mis_weight(p_l, p_b);
+                want_shadow = true;
+                q0 = make_float4(up_o.x, up_o.y, up_o.z, path_bits);
+                q1 = make_float4(dl.x, dl.y, dl.z, 0.0f);
+                q2 = make_float4(c.x, c.y, c.z, 0.0f);
+            }
+        }
+
+        // sample the next direction
+        const float u_mix = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedMix);
+        f3 wi;
+        if (u_mix < p_spec) {
+            const f3 hv3 = ggx_sample_vndf(ns, wo, alpha, u1, u2);
+            wi = normalize(hv3 * (2.0f * dot(wo, hv3)) - wo);
+        } else {
+            const float r = sqrtf(u1), phi = 6.283185307f * u2;
+            float sn, cs;
+            sincos_2pi(phi, sn, cs);
+            const float lx = r * cs, ly = r * sn, oz = 1.0f - u1;
+            const float lz = sqrtf(0.0f < oz ? oz : 0.0f);
+            f3 tt, bb;
+            create_basis(ns, tt, bb);
+            wi = normalize((tt * lx + bb * ly) + ns * lz);
+        }
+        f3 fb; float pdf;
+        if (dot(wi, ng) > 0.0f && bsdf_eval(ns, wo, wi, diff, f0, a2, p_spec, fb, pdf) && pdf > 0.0f) {
+            const float wgt = dot(ns, wi) / pdf;
+            thr = thr * (fb * wgt);
+            new_d = wi;
+            new_o = up_o;
+            next_pdf = pdf;
+        } else {
+            done = true;
+        }
+    }
+    // Russian roulette
+    if (!done && depth >= 3u) {
+        float pr = fmaxf(thr.x, fmaxf(thr.y, thr.z));
+        if (pr > 1.0f) pr = 1.0f;
+        if (pr < 0.05f) pr = 0.05f;
+        if (rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedRr) >= pr) done = true;
+        else thr = thr * (1.0f / pr);
+    }
+    if (!done && !(finite3(thr) && finite3(new_d))) done = true;
+}
+
 // `order` (optional): the queue positions grouped by the material class of their hit (k_material_sort): thread s of
 // the launch then shades ray order[s], so that a wave holds one kind of work -- sky, opaque lobes, glass.
 __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev f, ImagesDev img, uint32_t depth,
@@ -887,239 +1105,44 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
         const uint32_t acc = f.mean_base + sample;
         const uint32_t rng_acc = acc + f.rng_offset;
         const float prev_pdf = r2.w;      // solid-angle pdf the BSDF sampling gave this direction; <= 0: camera ray or delta lobe
-        f3 thr = mk3(r2.x, r2.y, r2.z);
-        f3 add = mk3(0.0f, 0.0f, 0.0f);
-        bool have_add = false;
-        f3 gb_normal = mk3(0.0f, 0.0f, 0.0f);
-        float gb_dist = 3.402823466e+38f;
-        bool done = false;
-        float next_pdf = 0.0f;
-        f3 new_o = o, new_d = dir;
-        uint32_t id_inst = 0xFFFFFFFFu, id_prim = 0xFFFFFFFFu;
+        LitState S;
+        S.thr = mk3(r2.x, r2.y, r2.z); S.add = mk3(0.0f, 0.0f, 0.0f); S.have_add = false;
+        S.gb_normal = mk3(0.0f, 0.0f, 0.0f); S.gb_dist = 3.402823466e+38f;
+        S.done = false; S.next_pdf = 0.0f; S.new_o = o; S.new_d = dir;
+        S.id_inst = 0xFFFFFFFFu; S.id_prim = 0xFFFFFFFFu; S.was_hit = false; S.want_shadow = false;
         if (tri == 0xFFFFFFFFu) {
-            add = thr * sky_color(dir);
-            have_add = true;
-            done = true;
+            S.add = S.thr * sky_color(dir);
+            S.have_add = true;
+            S.done = true;
         } else {
-            was_hit = true;
-            const f3 va = mk3(t0.x, t0.y, t0.z), vb = mk3(t1.x, t1.y, t1.z), vc = mk3(t2.x, t2.y, t2.z);
-            float hu, hv;
-            tri_uv(o, dir, va, vb, vc, hu, hv);
-            const float bx = 1.0f - hu - hv, by = hu, bz = hv;
-            const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
-            f3 ns = normalize((n0 * bx + n1 * by) + n2 * bz);
-            f3 ng = normalize(cross(vb - va, vc - va));
-            bool front = true;
-            if (dot(ng, dir) > 0.0f) { ng = ng * -1.0f; front = false; }
-            if (dot(ns, ng) < 0.0f) ns = ns * -1.0f;
-            const float tu = (s2.y * bx + s2.w * by) + s3.y * bz;
-            const float tv = (s2.z * bx + s3.x * by) + s3.z * bz;
-            const f3 P = o + dir * hr.x;
-            const LitMaterial lm = sc.lit_materials[__float_as_uint(s4.w)];
-            f3 albedo = mk3(t2.w, s3.w, s4.x);
-            const uint32_t tex = __float_as_uint(t0.w);
-            if (tex != 0xFFFFFFFFu) {
-                f3 tx = tex < kLdsTextures ? sample_texture(s_tex[tex], s_lut, tu, tv) : sample_texture(sc.textures[tex], s_lut, tu, tv);
-                albedo = tx * albedo;
-            }
-            if (lm.normal_texture) {
-                // glTF normalTexture (oracle: raygen_pixel_lit): tangent-space normal, +Y up, the frame derived from the
-                // triangle -- T along dP/du, B along -dP/dv, both made orthogonal to the shading normal; a degenerate uv
-                // mapping or a perturbed normal below the geometric surface leaves the shading normal as it is
-                const uint32_t nt = lm.normal_texture - 1u;
-                const f3 tn = nt < kLdsTextures ? sample_texture(s_tex[nt], s_lut, tu, tv) : sample_texture(sc.textures[nt], s_lut, tu, tv);
-                const float mx = tn.x * 2.0f - 1.0f, my = tn.y * 2.0f - 1.0f, mz = tn.z * 2.0f - 1.0f;
-                const f3 e1 = vb - va, e2 = vc - va;
-                const float du1 = s2.w - s2.y, dv1 = s3.x - s2.z, du2 = s3.y - s2.y, dv2 = s3.z - s2.z;
-                const float det = du1 * dv2 - du2 * dv1;
-                const float sg = det < 0.0f ? -1.0f : 1.0f;
-                f3 tt = (e1 * dv2 - e2 * dv1) * sg;
-                const f3 bt = (e1 * du2 - e2 * du1) * sg;
-                tt = tt - ns * dot(ns, tt);
-                const float tl2 = dot(tt, tt);
-                if (det != 0.0f && tl2 > 0.0f && isfinite(tl2)) {
-                    tt = tt * (1.0f / sqrtf(tl2));
-                    f3 bb = cross(ns, tt);
-                    if (dot(bb, bt) < 0.0f) bb = bb * -1.0f;
-                    f3 np = (tt * mx + bb * my) + ns * mz;
-                    const float nl2 = dot(np, np);
-                    if (nl2 > 0.0f && isfinite(nl2)) {
-                        np = np * (1.0f / sqrtf(nl2));
-                        if (dot(np, ng) > 0.0f) ns = np;
-                    }
-                }
-            }
-            const f3 wo = dir * -1.0f;
-            const f3 up_o = P + ng * f.normal_eps;
-            gb_normal = ns;
-            gb_dist = length(up_o - o);
-            if (depth == 0 && sample == f.ids_sample) { id_inst = __float_as_uint(s4.y); id_prim = __float_as_uint(s4.z); }
-
-            if (lm.emissive[0] > 0.0f || lm.emissive[1] > 0.0f || lm.emissive[2] > 0.0f) {
-                f3 em = mk3(lm.emissive[0], lm.emissive[1], lm.emissive[2]);
-                if (lm.emissive_texture) {
-                    const uint32_t et = lm.emissive_texture - 1u;
-                    em = em * (et < kLdsTextures ? sample_texture(s_tex[et], s_lut, tu, tv) : sample_texture(sc.textures[et], s_lut, tu, tv));
-                }
-                const f3 le = thr * em;
-                if (!(prev_pdf > 0.0f)) {
-                    add = le;
-                    have_add = true;
-                } else if (sc.n_lights) {
-                    // the light sampling of the previous vertex could have produced this point too
-                    const float cos_l = fabsf(dot(ng, dir));
-                    const float p_l = (lm.pdf_area * (hr.x * hr.x)) / cos_l;
-                    add = le * lit_mis_weight(prev_pdf, p_l);
-                    have_add = true;
-                }
-            }
-            const float u_lobe = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedLobe);
-            const float u1 = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedU1);
-            const float u2 = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedU2);
-            if (lm.transmission > 0.0f && u_lobe < lm.transmission) {
-                // smooth dielectric
-                const float ior = lm.ior;
-                const float eta = front ? 1.0f / ior : ior;
-                float cosi = dot(wo, ns);
-                if (cosi < 0.0f) cosi = 0.0f;
-                if (cosi > 1.0f) cosi = 1.0f;
-                const float sin2t = (eta * eta) * (1.0f - cosi * cosi);
-                bool reflect = true;
-                float cost = 0.0f;
-                if (sin2t < 1.0f) {
-                    cost = sqrtf(1.0f - sin2t);
-                    float r0s = (1.0f - ior) / (1.0f + ior);
-                    r0s = r0s * r0s;
-                    const float c = front ? cosi : cost;
-                    const float fr = r0s + (1.0f - r0s) * pow5(1.0f - c);
-                    reflect = u1 < fr;
-                }
-                if (reflect) {
-                    new_d = normalize(dir + ns * (2.0f * cosi));
-                    new_o = up_o;
-                } else {
-                    new_d = normalize(dir * eta + ns * (eta * cosi - cost));
-                    new_o = P - ng * f.normal_eps;
-                    thr = thr * albedo;
-                }
-                next_pdf = 0.0f;
-            } else {
-                float rough = t1.w, metal = lm.metallic;
-                if (lm.mr_texture) {        // glTF: G = roughness, B = metallic, linear texels, multiplied into the factors
-                    const uint32_t mt = lm.mr_texture - 1u;
-                    const f3 mr = mt < kLdsTextures ? sample_texture(s_tex[mt], s_lut, tu, tv) : sample_texture(sc.textures[mt], s_lut, tu, tv);
-                    rough = rough * mr.y;
-                    metal = metal * mr.z;
-                }
-                float alpha = rough * rough;
-                if (alpha < 0.0025f) alpha = 0.0025f;
-                const float a2 = alpha * alpha;
-                const float om = 1.0f - metal;
-                const f3 f0 = mk3(0.04f * om + albedo.x * metal, 0.04f * om + albedo.y * metal, 0.04f * om + albedo.z * metal);
-                const f3 diff = albedo * om;
-                const float p_spec = 0.25f + 0.75f * metal;
-
-                // next-event estimation
-                if (sc.n_lights) {
-                    const float ul = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedLight);
-                    uint32_t lo = 0, hi = sc.n_lights;
-                    while (lo < hi) { uint32_t mid = (lo + hi) / 2u; if (sc.light_cdf[mid] <= ul) lo = mid + 1u; else hi = mid; }
-                    if (lo >= sc.n_lights) lo = sc.n_lights - 1u;
-                    const float4 *lp = reinterpret_cast<const float4 *>(sc.lights + lo);
-                    const float4 l0 = lp[0], l1 = lp[1], l2 = lp[2], l3 = lp[3];
-                    const float a = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedLu);
-                    const float b = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedLv);
-                    const float su = sqrtf(a);
-                    const float w0 = 1.0f - su, w1 = su * (1.0f - b), w2 = su * b;
-                    const f3 pl = (mk3(l0.x, l0.y, l0.z) * w0 + mk3(l1.x, l1.y, l1.z) * w1) + mk3(l2.x, l2.y, l2.z) * w2;
-                    const f3 dl = pl - up_o;
-                    const float dist2 = dot(dl, dl);
-                    const float inv_dist = 1.0f / sqrtf(dist2);
-                    const f3 wl = dl * inv_dist;
-                    const float cos_g = dot(ng, wl);
-                    const float cos_l = fabsf(dot(mk3(l3.x, l3.y, l3.z), wl));
-                    f3 fb; float p_b;
-                    if (dist2 > 0.0f && cos_g > 0.0f && cos_l > 0.0f && bsdf_eval(ns, wo, wl, diff, f0, a2, p_spec, fb, p_b)) {
-                        const float cos_s = dot(ns, wl);
-                        const float gterm = (cos_s * cos_l) / (dist2 * l0.w);
-                        const float p_l = (l0.w * dist2) / cos_l;
-                        f3 le_l = mk3(l1.w, l2.w, l3.w);
-                        const float4 l5 = lp[5];
-                        if (__float_as_uint(l5.z)) {
-                            const float4 l4 = lp[4];
-                            const uint32_t et = __float_as_uint(l5.z) - 1u;
-                            const float lu = (l4.x * w0 + l4.z * w1) + l5.x * w2;
-                            const float lv = (l4.y * w0 + l4.w * w1) + l5.y * w2;
-                            le_l = le_l * (et < kLdsTextures ? sample_texture(s_tex[et], s_lut, lu, lv) : sample_texture(sc.textures[et], s_lut, lu, lv));
-                        }
-                        const f3 c = (((thr * fb) * le_l) * gterm) * lit_mis_weight(p_l, p_b);
-                        want_shadow = true;
-                        q0 = make_float4(up_o.x, up_o.y, up_o.z, r0.w);
-                        q1 = make_float4(dl.x, dl.y, dl.z, 0.0f);
-                        q2 = make_float4(c.x, c.y, c.z, 0.0f);
-                    }
-                }
-
-                // sample the next direction
-                const float u_mix = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedMix);
-                f3 wi;
-                if (u_mix < p_spec) {
-                    const f3 hv3 = ggx_sample_vndf(ns, wo, alpha, u1, u2);
-                    wi = normalize(hv3 * (2.0f * dot(wo, hv3)) - wo);
-                } else {
-                    const float r = sqrtf(u1), phi = 6.283185307f * u2;
-                    float sn, cs;
-                    sincos_2pi(phi, sn, cs);
-                    const float lx = r * cs, ly = r * sn, oz = 1.0f - u1;
-                    const float lz = sqrtf(0.0f < oz ? oz : 0.0f);
-                    f3 tt, bb;
-                    create_basis(ns, tt, bb);
-                    wi = normalize((tt * lx + bb * ly) + ns * lz);
-                }
-                f3 fb; float pdf;
-                if (dot(wi, ng) > 0.0f && bsdf_eval(ns, wo, wi, diff, f0, a2, p_spec, fb, pdf) && pdf > 0.0f) {
-                    const float wgt = dot(ns, wi) / pdf;
-                    thr = thr * (fb * wgt);
-                    new_d = wi;
-                    new_o = up_o;
-                    next_pdf = pdf;
-                } else {
-                    done = true;
-                }
-            }
-            // Russian roulette
-            if (!done && depth >= 3u) {
-                float pr = fmaxf(thr.x, fmaxf(thr.y, thr.z));
-                if (pr > 1.0f) pr = 1.0f;
-                if (pr < 0.05f) pr = 0.05f;
-                if (rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedRr) >= pr) done = true;
-                else thr = thr * (1.0f / pr);
-            }
-            if (!done && !(finite3(thr) && finite3(new_d))) done = true;
+            lit_shade_hit(sc, f, s_tex, s_lut, depth, o, dir, uv_state, rng_acc, prev_pdf, hr.x, r0.w, depth == 0 && sample == f.ids_sample,
+                          t0, t1, t2, s0, s1, s2, s3, s4, S);
         }
 
+        was_hit = S.was_hit; want_shadow = S.want_shadow;
+        q0 = S.q0; q1 = S.q1; q2 = S.q2;
         // radiance so far: results[path] is this path's L, started at bounce 0
-        if (depth == 0 || have_add) {
+        if (depth == 0 || S.have_add) {
             float4 cur = depth == 0 ? make_float4(0.0f, 0.0f, 0.0f, 1.0f) : results[path];
-            if (have_add) { cur.x = cur.x + add.x; cur.y = cur.y + add.y; cur.z = cur.z + add.z; }
+            if (S.have_add) { cur.x = cur.x + S.add.x; cur.y = cur.y + S.add.y; cur.z = cur.z + S.add.z; }
             cur.w = 1.0f;
             results[path] = cur;
         }
         if (depth == 0) {
-            if (sample == f.ids_sample) img.ids[pix] = make_uint2(id_inst, id_prim);
+            if (sample == f.ids_sample) img.ids[pix] = make_uint2(S.id_inst, S.id_prim);
             if (acc == 0) {
                 float z_range = f.z_far - f.z_near;
-                float zn = (gb_dist - f.z_near) / z_range;
+                float zn = (S.gb_dist - f.z_near) / z_range;
                 zn = fminf(fmaxf(zn, 0.0f), 1.0f);
                 img.depth[pix] = zn;
-                img.normal[pix] = make_float4(gb_normal.x, gb_normal.y, gb_normal.z, 1.0f);
+                img.normal[pix] = make_float4(S.gb_normal.x, S.gb_normal.y, S.gb_normal.z, 1.0f);
             }
         }
-        if (!done && depth + 1u < f.max_depth) {
+        if (!S.done && depth + 1u < f.max_depth) {
             alive = true;
-            o0 = make_float4(new_o.x, new_o.y, new_o.z, r0.w);
-            o1 = make_float4(new_d.x, new_d.y, new_d.z, r1.w);
-            o2 = make_float4(thr.x, thr.y, thr.z, next_pdf);
+            o0 = make_float4(S.new_o.x, S.new_o.y, S.new_o.z, r0.w);
+            o1 = make_float4(S.new_d.x, S.new_d.y, S.new_d.z, r1.w);
+            o2 = make_float4(S.thr.x, S.thr.y, S.thr.z, S.next_pdf);
         }
     }
 
@@ -1135,6 +1158,107 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
     if (want_shadow) { shadow.org[sslot] = q0; shadow.dir[sslot] = q1; shadow.thr[sslot] = q2; }
     }
     if (threadIdx.x == 0 && s_hits) atomicAdd(&counters[kHitCounter], s_hits);      // block_reserve's barriers order the LDS adds before this read
+}
+
+// Fused tail of the lit integrator: k_tail's idea for PTX_INTEGRATOR_LIT.  From the first bounce whose expected queue is
+// short, ONE launch takes every remaining path to its end -- a lane owns a path: closest-hit walk (Traversal::step),
+// lit_shade_hit, the occlusion query of its light sample as a second scalar walk that stops at the first accepted
+// triangle, the next bounce.  A wavefront bounce is four launches here (extend, shade, any-hit extend, shadow resolve),
+// each at least the dependent chain of its slowest ray.  Radiance is summed in the order the wavefront stages use
+// (results[path] + emission, then + the unoccluded light sample, bounce by bounce), so the image keeps its bits.
+__global__ void __launch_bounds__(64) k_tail_lit(SceneDev sc, FrameDev f, uint32_t depth0, RayQueue rays,
+                                                 uint32_t *__restrict__ counters, float4 *__restrict__ results)
+{
+    __shared__ float s_lut[256];
+    __shared__ TexDesc s_tex[kLdsTextures];
+    __shared__ uint2 s_stack[kLdsStack * 64];
+    const uint32_t n = counters[depth0];
+    if (blockIdx.x * 64u >= n) return;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t w = lane; w < 256u; w += 64u) s_lut[w] = sc.srgb_lut[w];
+    {
+        const uint32_t nw = (sc.n_textures < kLdsTextures ? sc.n_textures : kLdsTextures) * (uint32_t)(sizeof(TexDesc) / 4);
+        for (uint32_t w = lane; w < nw; w += 64u)
+            reinterpret_cast<uint32_t *>(s_tex)[w] = reinterpret_cast<const uint32_t *>(sc.textures)[w];
+    }
+    __syncthreads();
+    uint2 ovf_store[kOvfStack];
+    LaneStack st;
+    st.lds = (lds_uint2 *)s_stack + lane;      // kExtendBlock == 64: the column stride of LaneStack
+    st.ovf = (prv_uint2 *)ovf_store;
+    st.sp = 0;
+    uint32_t n_hits = 0;
+    for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {
+        const uint32_t i = base + lane;
+        bool alive = i < n;
+        f3 o = mk3(0.0f, 0.0f, 0.0f), dir = o, thr = o;
+        float prev_pdf = 0.0f, path_bits = 0.0f;
+        uint32_t path = 0, uv_state = 0;
+        float4 L = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        if (alive) {
+            const float4 r0 = rays.org[i], r1 = rays.dir[i], r2 = rays.thr[i];
+            o = mk3(r0.x, r0.y, r0.z); dir = mk3(r1.x, r1.y, r1.z); thr = mk3(r2.x, r2.y, r2.z);
+            prev_pdf = r2.w; path_bits = r0.w;
+            path = __float_as_uint(r0.w); uv_state = __float_as_uint(r1.w);
+            L = results[path];          // depth0 >= 1: the path's radiance so far
+        }
+        const uint32_t sample = path / f.n_pixels;
+        const uint32_t rng_acc = (f.mean_base + sample) + f.rng_offset;
+        for (uint32_t depth = depth0; ; ++depth) {
+            const unsigned long long live = __ballot(alive);
+            if (live == 0ull) break;
+            // the queue lengths of the bounces that never get a queue: ptx_get_stats counts rays from them
+            if (depth > depth0 && lane == 0) atomicAdd(&counters[depth], (uint32_t)__popcll(live));
+            LitState S;
+            S.thr = thr; S.add = mk3(0.0f, 0.0f, 0.0f); S.have_add = false;
+            S.gb_normal = mk3(0.0f, 0.0f, 0.0f); S.gb_dist = 3.402823466e+38f;
+            S.done = false; S.next_pdf = 0.0f; S.new_o = o; S.new_d = dir;
+            S.id_inst = 0xFFFFFFFFu; S.id_prim = 0xFFFFFFFFu; S.was_hit = false; S.want_shadow = false;
+            if (alive) {
+                Traversal<LaneStack, false> tr;
+                tr.ng_mask = 0; tr.tg_mask = 0;
+                if (tr.init(sc.n_nodes, o, dir, f.t_min, f.t_max, st))
+                    while (!tr.step(sc.nodes, sc.tris, st)) {}
+                const uint32_t tri = tr.hit.tri;
+                if (tri == 0xFFFFFFFFu) {
+                    S.add = S.thr * sky_color(dir);
+                    S.have_add = true;
+                    S.done = true;
+                } else {
+                    ++n_hits;
+                    const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri);
+                    const float4 t0 = sp[0], t1 = sp[1], t2 = sp[2], s0 = sp[3], s1 = sp[4], s2 = sp[5], s3 = sp[6], s4 = sp[7];
+                    lit_shade_hit(sc, f, s_tex, s_lut, depth, o, dir, uv_state, rng_acc, prev_pdf, tr.hit.t, path_bits, false,
+                                  t0, t1, t2, s0, s1, s2, s3, s4, S);
+                }
+                if (S.have_add) { L.x = L.x + S.add.x; L.y = L.y + S.add.y; L.z = L.z + S.add.z; }
+            }
+            // the occlusion ray of this bounce's light sample (counted like the wavefront's occlusion queue)
+            const bool want = alive && S.want_shadow;
+            const unsigned long long wm = __ballot(want);
+            if (wm != 0ull && lane == 0) atomicAdd(&counters[kShadowCount + depth], (uint32_t)__popcll(wm));
+            if (want) {
+                Traversal<LaneStack, false> sh;
+                sh.ng_mask = 0; sh.tg_mask = 0;
+                bool occluded = false;
+                if (sh.init(sc.n_nodes, mk3(S.q0.x, S.q0.y, S.q0.z), mk3(S.q1.x, S.q1.y, S.q1.z), f.t_min, kLitShadowTmax, st))
+                    while (!sh.step(sc.nodes, sc.tris, st)) { if (sh.hit.tri != 0xFFFFFFFFu) break; }
+                occluded = sh.hit.tri != 0xFFFFFFFFu;
+                if (!occluded) { L.x = L.x + S.q2.x; L.y = L.y + S.q2.y; L.z = L.z + S.q2.z; }
+            }
+            if (alive) {
+                if (S.done || depth + 1u >= f.max_depth) {
+                    L.w = 1.0f;
+                    results[path] = L;
+                    alive = false;
+                } else {
+                    o = S.new_o; dir = S.new_d; thr = S.thr; prev_pdf = S.next_pdf;
+                }
+            }
+        }
+    }
+    const uint32_t h = wave_inclusive_sum(n_hits);       // lane 63 holds the wave's total
+    if (lane == 63u && h) atomicAdd(&counters[kHitCounter], h);
 }
 
 // Material sorting (BASELINE.json north_star: "ballot / prefix-sum primitives drive ray-queue compaction and material
@@ -1314,6 +1438,14 @@ void launch_tail(hipStream_t s, const SceneDev &sc, const FrameDev &f, uint32_t 
     uint32_t blocks = std::min((capacity + 63u) / 64u, 4096u);
     if (!blocks) return;
     hipLaunchKernelGGL(k_tail, dim3(blocks), dim3(64), 0, s, sc, f, depth0, rays, counters, results);
+}
+
+void launch_tail_lit(hipStream_t s, const SceneDev &sc, const FrameDev &f, uint32_t depth0, RayQueue rays, uint32_t *counters,
+                     uint32_t capacity, float4 *results)
+{
+    uint32_t blocks = std::min((capacity + 63u) / 64u, 4096u);
+    if (!blocks) return;
+    hipLaunchKernelGGL(k_tail_lit, dim3(blocks), dim3(64), 0, s, sc, f, depth0, rays, counters, results);
 }
 
 void launch_shade_lit(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,

@@ -346,3 +346,50 @@ def test_host_normal_and_emissive_textures(oracle, tmp_path):
     e["normal_texture"] = 0; e["emissive_texture"] = 1
     ctx.set_material_ext(0, e)                           # an emissive map may be sRGB
     ctx.close()
+
+
+def test_lit_fused_tail_equals_bounce_by_bounce(oracle, monkeypatch):
+    """The lit integrator's fused tail (k_tail_lit: a lane per path -- closest-hit walk, lit shading, the occlusion query of its
+    light sample -- from the first bounce whose expected queue is short) against the oracle and against the wavefront schedule
+    (PTX_TAIL_RAYS=0): image, ids, and the ray / hit / occlusion-ray counts, on the lit Cornell box (emitter, glass, metal)
+    and on the stress scene with hundreds of emitters, glass, metallic-roughness, normal and emissive maps."""
+    from path_tracer_amd import capi
+    stress = stress_scene(n_confetti=6000)
+    rng = np.random.default_rng(3)
+    for i in range(len(stress.materials)):
+        stress.materials[i]["metallic"] = np.float32([0.0, 1.0, 0.5, 0.0][i % 4])
+        if i % 7 == 0:
+            stress.material_ext[i]["emissive"] = rng.uniform(0.5, 4.0, 3).astype(np.float32)
+        if i % 5 == 1:
+            stress.material_ext[i]["transmission"] = np.float32(0.7)
+            stress.material_ext[i]["ior"] = np.float32(1.33)
+        if i % 3 == 0:
+            stress.material_ext[i]["mr_texture"] = (2 * i) % 70 + 1
+        if i % 2 == 1:
+            stress.material_ext[i]["normal_texture"] = (2 * i + 4) % 70 + 1
+        if i % 14 == 0:
+            stress.material_ext[i]["emissive_texture"] = (3 * i + 1) % 70 + 1
+    cases = ((cornell_lit(), oracle.SCENE_WORLD_NORMALS | oracle.SCENE_TEXTURE_TIMES_FACTOR, [0, 1.0, 3.9], 40, (160, 120), 12),
+             (stress, oracle.SCENE_WORLD_NORMALS, [0.0, 0.2, 4.5], 60, (128, 96), 8))
+    for ing, opts, pos, fov, (w, h), depth in cases:
+        sc = oracle.scene_from_ingest(ing, options=opts, with_material_ext=True)
+        cam = oracle.camera_matrices(pos, oracle.yaw_quat(0), np.deg2rad(np.float32(fov)), w / h, 0.1, 1000.0)
+        want = sc.render(cam, w, h, 6, SEED, params=oracle.default_params(max_depth=depth, integrator=oracle.INTEGRATOR_LIT))
+        P = capi.default_params(max_depth=depth, integrator=capi.INTEGRATOR_LIT)
+        outs = {}
+        for tail in (1 << 20, 0):
+            monkeypatch.setenv("PTX_TAIL_RAYS", str(tail))
+            ctx = capi.Context(0)
+            upload(ctx, ing, oracle, options=opts, with_material_ext=True)
+            gpu_render(ctx, oracle, cam, w, h, 2, params=P)       # learns the queue lengths
+            ctx.synchronize()
+            ctx.reset_stats()
+            got = gpu_render(ctx, oracle, cam, w, h, 6, params=P, batch=(tail == 0))
+            st = ctx.stats()
+            assert_images_bit_equal(got, want, "lit tail %d" % tail)
+            assert st["rays"] == want["stats"]["rays"] and st["hits"] == want["stats"]["hits"] and st["samples"] == want["stats"]["samples"]
+            assert st["shadow_rays"] == want["stats"]["shadow_rays"] > 0
+            assert (st["tail_launches"] > 0) == (tail > 0), st["tail_launches"]
+            outs[tail] = got
+            ctx.close()
+        assert_images_bit_equal(outs[1 << 20], outs[0], "lit tail vs bounce by bounce")
