@@ -333,3 +333,25 @@ def test_normal_and_emissive_textures_ingest_and_effect(oracle, tmp_path):
     gone.import_gltf(path)
     assert gone.material_ext["normal_texture"].tolist() == [0, 0] and gone.material_ext["emissive_texture"].tolist() == [0, 0]
     assert len(gone.textures) == 2
+
+
+def test_normal_map_tangent_frame_orientation(oracle, tmp_path):
+    """The tangent frame of the normal map (no tangents in the vertex format: derived from positions and uvs).  On the test
+    floor u runs along +x and glTF's v along +z: a texel that says +X in tangent space must tilt the shading normal towards
+    +x (T = dP/du), one that says +Y towards -z (B = -dP/dv: glTF's v runs downwards, the map's +Y is up), and the flat texel
+    (128, 128, 255) leaves the normal at +y to within its own quantisation."""
+    from helpers import write_mr_quad_gltf
+    from oracle.gltf_ingest import IngestedScene
+    path = write_mr_quad_gltf(str(tmp_path), with_maps=True)
+    ing = IngestedScene(ref_quirks=False)
+    ing.import_gltf(path)
+    assert ing.material_ext["normal_texture"][0] == 3
+    cam = oracle.camera_matrices([0, 1.2, 3.5], oracle.yaw_quat(0), np.deg2rad(np.float32(55)), 1.0, 0.1, 1000.0)
+    P = oracle.default_params(max_depth=2, integrator=oracle.INTEGRATOR_LIT)
+    opts = oracle.SCENE_WORLD_NORMALS | oracle.SCENE_TEXTURE_TIMES_FACTOR
+    for rgb, want in (((255, 128, 128), [1, 0, 0]), ((128, 255, 128), [0, 0, -1]), ((0, 128, 128), [-1, 0, 0]), ((128, 128, 255), [0, 1, 0])):
+        ing.textures[2] = (np.tile(np.uint8(list(rgb) + [255]), (4, 4, 1)), ing.textures[2][1])
+        r = oracle.scene_from_ingest(ing, options=opts, with_material_ext=True).render(cam, 32, 32, 1, SEED, params=P)
+        floor = r["ids"][..., 0] == 0
+        n = r["normal"][floor][:, :3]
+        assert floor.sum() > 100 and np.abs(n - np.float32(want)).max() < 0.02, (rgb, n[0])
