@@ -6,7 +6,9 @@
 //   cull:   1 = a stack entry carries its entry distance and is dropped at pop time when the closest hit has moved in front
 //           2 = the entry carries the entry distance of its PARENT node's quantisation frame (one value per node group, what
 //               fits the product's (group, mask) stack), truncated to the upper 16 bits of the float
-//           3 = the same with the parent's decoded box as seen by ITS parent (the distance of the child slot the walk came through)
+//           4 = one distance per pushed GROUP: the smallest entry distance of the node's hit inner children
+//           5 = one distance per pushed group: the smallest entry distance of the children that stay on the stack (the nearest
+//               in pop order is taken at once)
 // Counts node visits and triangle tests per ray.  Same triangle test as the product (pt_math.h).
 #include "../../path_tracer_amd/csrc/bvh8.h"
 #include "../../path_tracer_amd/csrc/bvh_quant.h"
@@ -28,7 +30,9 @@ struct Lab {
 };
 }
 
+static int g_delay = 0;     // triangle tests of a leaf hit happen `g_delay` node visits later (the kernels' wave-level triangle queue tests them in blocks)
 extern "C" {
+void tlab_set_delay(int d) { g_delay = d; }
 void *tlab_create(void *bvh_handle, const float *verts)
 {
     Lab *L = new Lab;
@@ -82,8 +86,26 @@ void tlab_trace(void *h, const float *rays, uint64_t n, float t_min, float t_max
         st.clear();
         if (!bvh.nodes.empty() && !(oct & kRayDegenerate)) st.push_back({0u, t_min});
         const uint32_t octinv = oct & 7u;
-        while (!st.empty()) {
+        struct Pend { uint32_t tri; int due; };
+        std::vector<Pend> pend;
+        int visit = 0;
+        auto run_tests = [&](bool all) {
+            size_t w = 0;
+            for (size_t q = 0; q < pend.size(); ++q) {
+                if (!all && pend[q].due > visit) { pend[w++] = pend[q]; continue; }
+                const TriRec &tr = L.tris[pend[q].tri];
+                out[3]++;
+                float t, u, v;
+                if (tri_test(o, d, mk3(tr.v0[0], tr.v0[1], tr.v0[2]), mk3(tr.v1[0], tr.v1[1], tr.v1[2]), mk3(tr.v2[0], tr.v2[1], tr.v2[2]), t_min, t_max, t, u, v) &&
+                    hit_better(t, tr.instance, tr.prim, best, bi, bp)) { best = t; bi = tr.instance; bp = tr.prim; hit = true; }
+            }
+            pend.resize(w);
+        };
+        while (!st.empty() || !pend.empty()) {
+            if (st.empty()) { run_tests(true); continue; }
+            run_tests(false);
             Ent e = st.back(); st.pop_back();
+            ++visit;
             if (cull && e.t > best) continue;
             const Bvh8Node &nd = bvh.nodes[e.node];
             out[2]++;
@@ -123,21 +145,19 @@ void tlab_trace(void *h, const float *rays, uint64_t n, float t_min, float t_max
                 int s = hits[k].s;
                 if ((nd.imask >> s) & 1u) continue;
                 uint32_t off = nd.meta[s] & 31u, cnt = bq_popc((uint32_t)nd.meta[s] >> 5);
-                for (uint32_t q = 0; q < cnt; ++q) {
-                    const TriRec &tr = L.tris[nd.tri_base + off + q];
-                    out[3]++;
-                    float t, u, v;
-                    if (tri_test(o, d, mk3(tr.v0[0], tr.v0[1], tr.v0[2]), mk3(tr.v1[0], tr.v1[1], tr.v1[2]), mk3(tr.v2[0], tr.v2[1], tr.v2[2]), t_min, t_max, t, u, v) &&
-                        hit_better(t, tr.instance, tr.prim, best, bi, bp)) { best = t; bi = tr.instance; bp = tr.prim; hit = true; }
-                }
+                for (uint32_t q = 0; q < cnt; ++q) pend.push_back({nd.tri_base + off + q, visit + g_delay});
+                if (g_delay == 0) run_tests(true);
             }
             C inner[8]; int ni = 0;
             for (int k = 0; k < nh; ++k) if ((nd.imask >> hits[k].s) & 1u) inner[ni++] = hits[k];
             if (order == 0) std::sort(inner, inner + ni, [&](const C &a, const C &b) { return ((a.s ^ octinv)) < ((b.s ^ octinv)); });   // pop order: highest (slot ^ octinv) first
             else std::sort(inner, inner + ni, [](const C &a, const C &b) { return a.t > b.t; });                                       // far first -> near popped first
+            float t_all = INFINITY, t_rest = INFINITY;
+            for (int k = 0; k < ni; ++k) { t_all = fminf(t_all, inner[k].t); if (k + 1 < ni) t_rest = fminf(t_rest, inner[k].t); }
             for (int k = 0; k < ni; ++k) {
                 int s = inner[k].s;
-                st.push_back({nd.child_base + bq_popc(nd.imask & ((1u << s) - 1u)), cull == 2 ? t_frame : inner[k].t});
+                float tt = cull == 2 ? t_frame : cull == 4 ? t_all : cull == 5 ? (k + 1 < ni ? t_rest : t_min) : inner[k].t;
+                st.push_back({nd.child_base + bq_popc(nd.imask & ((1u << s) - 1u)), tt});
             }
         }
         if (hit) out[1]++;

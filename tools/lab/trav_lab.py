@@ -54,9 +54,16 @@ dx = ((xs + 0.5) / W * 2 - 1) * th * W / H; dy = (1 - (ys + 0.5) / H * 2) * th
 dirs = np.stack([np.ones_like(dx), dy, dx], -1).reshape(-1, 3); dirs /= np.linalg.norm(dirs, axis=1)[:, None]
 prim = np.ascontiguousarray(np.concatenate([np.tile(np.float32([-8, 1.6, 0]), (len(dirs), 1)), dirs], 1), np.float32)
 print("tris", len(v), "nodes", nn.value)
+for delay in (0, 1, 2, 4):
+    L.tlab_set_delay(delay)
+    for label, rays in (("bounce", bounce), ("primary", prim)):
+        o = (C.c_uint64 * 4)()
+        L.tlab_trace(T, rays.ctypes.data, len(rays), 1e-3, 1e4, 0, 0, 0, o)
+        print("%-8s triangle tests %d node visits after the leaf hit: nodes/ray %6.2f tris/ray %5.2f" % (label, delay, o[2] / o[0], o[3] / o[0]))
+L.tlab_set_delay(0)
 for label, rays in (("bounce", bounce), ("primary", prim)):
     for boxes, order, cull, what in ((0, 0, 0, "product: 8-bit planes, octant order"), (0, 1, 0, "8-bit, distance order"), (0, 0, 1, "8-bit, octant order, stale culling"),
-                                     (0, 1, 1, "8-bit, distance order, stale culling"), (0, 0, 2, "8-bit, octant order, group culling by the parent frame"), (2, 0, 0, "11-bit planes, octant order"), (1, 0, 0, "exact boxes, octant order"),
+                                     (0, 1, 1, "8-bit, distance order, stale culling"), (0, 0, 2, "8-bit, octant order, group culling by the parent frame"), (0, 0, 4, "8-bit, octant, group = min over hit inner children"), (0, 0, 5, "8-bit, octant, group = min over the children left on the stack"), (2, 0, 0, "11-bit planes, octant order"), (1, 0, 0, "exact boxes, octant order"),
                                      (1, 1, 1, "exact boxes, distance order, stale culling")):
         o = (C.c_uint64 * 4)()
         L.tlab_trace(T, rays.ctypes.data, len(rays), 1e-3, 1e4, boxes, order, cull, o)
