@@ -324,6 +324,8 @@ def main():
         cpu = None
         parity = None
         cpu_spp = args.cpu_baseline_spp if args.cpu_baseline_spp >= 0 else max(1, min(32, round(4 * 1920 * 1080 / (W * H))))
+        if world > 1 and args.cpu_baseline_spp < 0:
+            cpu_spp = 0          # the CPU leg belongs to the N = 1 line; with more ranks the others would only wait for it
         if cpu_spp > 0:
             cpu, parity = cpu_baseline(r, wl, assets, W, H, cpu_spp, args.max_depth, args.workload, lit)
 
