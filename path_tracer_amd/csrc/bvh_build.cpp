@@ -234,6 +234,8 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
     // slots on the Sponza stand-in), and every visit pays for all 8 slots.
     const uint32_t n2 = b2.n_nodes.load();
     const float c_node = env_float("PTX_BVH_CNODE", 1.8f), c_prim = env_float("PTX_BVH_CPRIM", 1.0f);
+    // developer experiment (tools/lab/trav_lab.py): nodes of at most W children in the same node format
+    const int W = std::max(2, std::min(8, (int)env_float("PTX_LAB_BVH_WIDTH", 8.0f)));
     const float inf = std::numeric_limits<float>::infinity();
     struct Dp { float c[8]; uint8_t k[9]; uint8_t leaf; };      // c[i], i = 1..7; k[j], j = 2..8: slots given to the left child
     std::vector<Dp> dp(n2);
@@ -257,9 +259,10 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
                 float v = L.c[k] + R.c[j - k];
                 if (v < best) { best = v; bk = k; }
             }
+            if (j > W) best = inf;
             dist[j] = best; d.k[j] = (uint8_t)bk;
         }
-        float c_internal = dist[8] + area * c_node;
+        float c_internal = dist[W] + area * c_node;
         d.leaf = c_leaf <= c_internal;
         d.c[1] = d.leaf ? c_leaf : c_internal;
         for (int i = 2; i <= 7; ++i) d.c[i] = std::min(dist[i], d.c[i - 1]);
@@ -301,9 +304,9 @@ bool build_bvh8(const float *verts, size_t n_tris, Bvh8 &out, int n_threads)
                 if (src.count > 0 || dp[w.node2].leaf) {
                     kids[nk++] = w.node2;             // a leaf root becomes the single leaf slot
                 } else {
-                    int k = dp[w.node2].k[8];
+                    int k = dp[w.node2].k[W];
                     gather.run(src.left, k, kids, nk);
-                    gather.run(src.right, 8 - k, kids, nk);
+                    gather.run(src.right, W - k, kids, nk);
                 }
                 // slot assignment: slot s is visited first by rays whose direction is negative exactly
                 // on the axes whose bit is set in s (bit2 = x, bit1 = y, bit0 = z), so it should hold the
