@@ -1075,21 +1075,31 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
         for (uint32_t w = threadIdx.x; w < nw; w += kShadeBlock)
             reinterpret_cast<uint32_t *>(s_tex)[w] = reinterpret_cast<const uint32_t *>(sc.textures)[w];
     }
+    // The next tile's ray + hit are fetched behind this tile's shading, in front of its two queue reservations (two atomic
+    // round trips, five barriers): one of a tile's dependent round trips leaves the critical path, and no register is
+    // held across the shading itself (124 VGPRs keep two blocks per CU).
+    const float4 kZero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    auto fetch_ray = [&](uint32_t tile_, float4 &a0, float4 &a1, float4 &a2, float2 &h) {
+        const uint32_t slot_ = tile_ * kShadeBlock + threadIdx.x;
+        a0 = kZero4; a1 = kZero4; a2 = kZero4; h = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
+        if ((uint64_t)tile_ * kShadeBlock >= n_live) return;
+        const bool valid_ = slot_ < capacity && slot_ < n_live;
+        const uint32_t i_ = (order && valid_) ? order[slot_] : slot_;
+        if (i_ < capacity) {
+            a1 = rays_in.dir[i_];
+            // camera rays: origin, path index (= queue index) and unit throughput (rgen.glsl:62) are never stored
+            a0 = depth == 0 ? make_float4(f.cam_origin[0], f.cam_origin[1], f.cam_origin[2], __uint_as_float(i_)) : rays_in.org[i_];
+            a2 = depth == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : rays_in.thr[i_];
+            h = *reinterpret_cast<const float2 *>(hits + i_);
+        }
+    };
+    float4 r0, r1, r2; float2 hr;
+    fetch_ray(blockIdx.x, r0, r1, r2, hr);
     for (uint32_t tile = blockIdx.x; (uint64_t)tile * kShadeBlock < n_live; tile += gridDim.x) {
     const uint32_t slot_in = tile * kShadeBlock + threadIdx.x;
     const bool valid = slot_in < capacity && slot_in < n_live;
-    const uint32_t i = (order && valid) ? order[slot_in] : slot_in;
-    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
-    float2 hr = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
-    if (i < capacity) {
-        r1 = rays_in.dir[i];
-        // camera rays: origin, path index (= queue index) and unit throughput (rgen.glsl:62) are never stored
-        r0 = depth == 0 ? make_float4(f.cam_origin[0], f.cam_origin[1], f.cam_origin[2], __uint_as_float(i)) : rays_in.org[i];
-        r2 = depth == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : rays_in.thr[i];
-        hr = *reinterpret_cast<const float2 *>(hits + i);
-    }
     const uint32_t tri = valid ? __float_as_uint(hr.y) : 0xFFFFFFFFu;
-    float4 t0 = r0, t1 = r0, t2 = r0, s0 = r0, s1 = r0, s2 = r0, s3 = r0, s4 = r0;
+    float4 t0 = kZero4, t1 = kZero4, t2 = kZero4, s0 = kZero4, s1 = kZero4, s2 = kZero4, s3 = kZero4, s4 = kZero4;
     if (tri != 0xFFFFFFFFu) {
         const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri);
         t0 = sp[0]; t1 = sp[1]; t2 = sp[2]; s0 = sp[3]; s1 = sp[4]; s2 = sp[5]; s3 = sp[6]; s4 = sp[7];
@@ -1146,6 +1156,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
         }
     }
 
+    fetch_ray(tile + gridDim.x, r0, r1, r2, hr);      // this tile's ray registers are dead: everything it produced is in o0 .. q2
     BlockScan bs; bs.wave_cnt = s_cnt; bs.base = &s_base;
     {
         // hits of the block: LDS atomic per wave, one global atomic per block (a single word takes ~88 M atomics/s)
