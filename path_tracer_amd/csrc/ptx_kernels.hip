@@ -837,6 +837,7 @@ __device__ __forceinline__ uint32_t block_reserve(bool flag, const BlockScan &bs
 // One hit of the lit integrator (oracle: raygen_pixel_lit, the `hit` branch): emission, one next-event-estimation sample
 // (its occlusion ray comes back in q0 .. q2), BSDF sampling, Russian roulette.  Shared by the wavefront stage (k_shade_lit)
 // and the fused tail (k_tail_lit): one set of expression trees, so both give the oracle's bits.
+constexpr uint32_t kLdsCdf = 4096;          // entries of k_shade_lit's LDS light table (16 KB)
 struct LitState {
     f3 thr, add, gb_normal, new_o, new_d;
     float gb_dist, next_pdf;
@@ -846,7 +847,7 @@ struct LitState {
 };
 __device__ __forceinline__ void lit_shade_hit(const SceneDev &sc, const FrameDev &f, const TexDesc *s_tex, const float *s_lut,
                                               uint32_t depth, f3 o, f3 dir, uint32_t uv_state, uint32_t rng_acc, float prev_pdf,
-                                              float hit_t, float path_bits, bool want_ids,
+                                              float hit_t, float path_bits, bool want_ids, const float *lds_cdf, uint32_t cdf_stride,
                                               const float4 &t0, const float4 &t1, const float4 &t2, const float4 &s0,
                                               const float4 &s1, const float4 &s2, const float4 &s3, const float4 &s4, LitState &S)
 {
@@ -976,7 +977,20 @@ __device__ __forceinline__ void lit_shade_hit(const SceneDev &sc, const FrameDev
         // next-event estimation
         if (sc.n_lights) {
             const float ul = rand_from(uv_state, depth, rng_acc, f.seed + kLitSeedLight);
+            // first light whose cumulative probability exceeds ul (the oracle's binary search: the CDF is monotone, so any
+            // search for that index agrees).  With the block's LDS table -- the last CDF value of every `cdf_stride` lights,
+            // the whole CDF when there are no more than kLdsCdf -- the dozen dependent global loads of a plain binary search
+            // become LDS reads plus log2(cdf_stride) global steps.
             uint32_t lo = 0, hi = sc.n_lights;
+            if (lds_cdf) {
+                const uint32_t nb = (sc.n_lights + cdf_stride - 1u) / cdf_stride;
+                uint32_t bl = 0, bh = nb;
+                while (bl < bh) { uint32_t mid = (bl + bh) / 2u; if (lds_cdf[mid] <= ul) bl = mid + 1u; else bh = mid; }
+                lo = bl * cdf_stride;
+                hi = lo + cdf_stride < sc.n_lights ? lo + cdf_stride : sc.n_lights;
+                if (bl >= nb) { lo = sc.n_lights; hi = sc.n_lights; }
+                if (cdf_stride == 1u) hi = lo;          // the table is the CDF itself
+            }
             while (lo < hi) { uint32_t mid = (lo + hi) / 2u; if (sc.light_cdf[mid] <= ul) lo = mid + 1u; else hi = mid; }
             if (lo >= sc.n_lights) lo = sc.n_lights - 1u;
             const float4 *lp = reinterpret_cast<const float4 *>(sc.lights + lo);
@@ -1064,11 +1078,17 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
     __shared__ TexDesc s_tex[kLdsTextures];
     __shared__ uint32_t s_cnt[kShadeBlock / 64];
     __shared__ uint32_t s_base, s_hits;
+    __shared__ float s_cdf[kLdsCdf];        // light pick: last CDF value of every cdf_stride lights (see lit_shade_hit)
 
     // capped grid, tiles of kShadeBlock rays (see k_shade)
     const uint32_t n_live = counters[depth];
     if ((uint64_t)blockIdx.x * kShadeBlock >= n_live) return;
     if (threadIdx.x == 0) s_hits = 0;
+    const uint32_t cdf_stride = (sc.n_lights + kLdsCdf - 1u) / kLdsCdf > 0u ? (sc.n_lights + kLdsCdf - 1u) / kLdsCdf : 1u;
+    for (uint32_t j = threadIdx.x; j * cdf_stride < sc.n_lights; j += kShadeBlock) {
+        const uint32_t last = (j + 1u) * cdf_stride - 1u;
+        s_cdf[j] = sc.light_cdf[last < sc.n_lights ? last : sc.n_lights - 1u];
+    }
     if (threadIdx.x < 256) s_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];
     {
         const uint32_t nw = (sc.n_textures < kLdsTextures ? sc.n_textures : kLdsTextures) * (uint32_t)(sizeof(TexDesc) / 4);
@@ -1126,7 +1146,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
             S.done = true;
         } else {
             lit_shade_hit(sc, f, s_tex, s_lut, depth, o, dir, uv_state, rng_acc, prev_pdf, hr.x, r0.w, depth == 0 && sample == f.ids_sample,
-                          t0, t1, t2, s0, s1, s2, s3, s4, S);
+                          sc.n_lights ? s_cdf : nullptr, cdf_stride, t0, t1, t2, s0, s1, s2, s3, s4, S);
         }
 
         was_hit = S.was_hit; want_shadow = S.want_shadow;
@@ -1240,7 +1260,7 @@ __global__ void __launch_bounds__(64) k_tail_lit(SceneDev sc, FrameDev f, uint32
                     const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri);
                     const float4 t0 = sp[0], t1 = sp[1], t2 = sp[2], s0 = sp[3], s1 = sp[4], s2 = sp[5], s3 = sp[6], s4 = sp[7];
                     lit_shade_hit(sc, f, s_tex, s_lut, depth, o, dir, uv_state, rng_acc, prev_pdf, tr.hit.t, path_bits, false,
-                                  t0, t1, t2, s0, s1, s2, s3, s4, S);
+                                  nullptr, 1u, t0, t1, t2, s0, s1, s2, s3, s4, S);
                 }
                 if (S.have_add) { L.x = L.x + S.add.x; L.y = L.y + S.add.y; L.z = L.z + S.add.z; }
             }

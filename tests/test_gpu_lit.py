@@ -393,3 +393,25 @@ def test_lit_fused_tail_equals_bounce_by_bounce(oracle, monkeypatch):
             outs[tail] = got
             ctx.close()
         assert_images_bit_equal(outs[1 << 20], outs[0], "lit tail vs bounce by bounce")
+
+
+def test_lit_many_lights_two_level_cdf(oracle, gpu_ctx_factory):
+    """More emissive triangles than k_shade_lit's LDS light table holds (4096): the light pick goes through the table of
+    bucket maxima and finishes with a short binary search in the global CDF -- the same index as the oracle's plain search."""
+    from path_tracer_amd import capi
+    ing = stress_scene(n_confetti=42000)
+    rng = np.random.default_rng(5)
+    for i in range(len(ing.materials)):
+        if i % 2 == 0:
+            ing.material_ext[i]["emissive"] = rng.uniform(0.2, 3.0, 3).astype(np.float32)
+    ctx = gpu_ctx_factory()
+    upload(ctx, ing, oracle, options=capi.SCENE_WORLD_NORMALS, with_material_ext=True)
+    sc = oracle.scene_from_ingest(ing, options=oracle.SCENE_WORLD_NORMALS, with_material_ext=True)
+    assert len(sc.lights()) > 3 * 4096
+    cam = oracle.camera_matrices([0.0, 0.2, 4.5], oracle.yaw_quat(0), np.deg2rad(np.float32(60)), 1.0, 0.1, 1000.0)
+    ctx.reset_stats()
+    want = sc.render(cam, 96, 96, 3, SEED, params=oracle.default_params(max_depth=5, integrator=oracle.INTEGRATOR_LIT))
+    got = gpu_render(ctx, oracle, cam, 96, 96, 3, params=capi.default_params(max_depth=5, integrator=capi.INTEGRATOR_LIT))
+    assert_images_bit_equal(got, want, "lit, > 12 k lights")
+    st = ctx.stats()
+    assert st["lights"] == len(sc.lights()) and st["shadow_rays"] == want["stats"]["shadow_rays"] > 0
