@@ -165,3 +165,22 @@ def test_random_soups_bit_exact(oracle, gpu_ctx_factory, seed):
         assert_images_bit_equal(got, want, "random soup %d view %d (%dx%d depth %d spp %d)" % (seed, k, w, h, depth, spp))
         st = ctx.stats()
         assert st["rays"] == want["stats"]["rays"] and st["hits"] == want["stats"]["hits"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width", [2, 3, 5])
+def test_closest_hits_do_not_depend_on_the_tree(oracle, gpu_ctx_factory, monkeypatch, width):
+    """The image is a property of the scene, not of the acceleration structure: with the builder collapsing to nodes of at
+    most 2 / 3 / 5 children (PTX_LAB_BVH_WIDTH, a developer switch; deeper trees, other groupings, other stack depths) the
+    textured lion + boulder render must still equal the oracle bit for bit."""
+    from path_tracer_amd import capi
+    monkeypatch.setenv("PTX_LAB_BVH_WIDTH", str(width))
+    ing = lion_boulder()
+    ctx = gpu_ctx_factory()
+    upload(ctx, ing, oracle)
+    sc = oracle.scene_from_ingest(ing)
+    cam = oracle.camera_matrices([2.0, 0.25, 0.6], oracle.yaw_quat(0), np.deg2rad(np.float32(70)), 16 / 9, 0.1, 1000.0)
+    want = sc.render(cam, 160, 90, 2, SEED, params=oracle.default_params(max_depth=6))
+    got = gpu_render(ctx, oracle, cam, 160, 90, 2, params=capi.default_params(max_depth=6))
+    assert_images_bit_equal(got, want, "tree width %d" % width)
+    assert ctx.stats()["bvh_nodes"] > (40000 if width == 2 else 15000)
