@@ -30,9 +30,11 @@ struct Lab {
 };
 }
 
+static unsigned long long g_cull_first = 0, g_cull_later = 0;
 static int g_delay = 0;     // triangle tests of a leaf hit happen `g_delay` node visits later (the kernels' wave-level triangle queue tests them in blocks)
 extern "C" {
 void tlab_set_delay(int d) { g_delay = d; }
+void tlab_cull_counts(unsigned long long *o) { o[0] = g_cull_first; o[1] = g_cull_later; g_cull_first = g_cull_later = 0; }
 void *tlab_create(void *bvh_handle, const float *verts)
 {
     Lab *L = new Lab;
@@ -75,7 +77,7 @@ void tlab_trace(void *h, const float *rays, uint64_t n, float t_min, float t_max
     Lab &L = *(Lab *)h;
     const Bvh8 &bvh = *L.bvh;
     for (int k = 0; k < 4; ++k) out[k] = 0;
-    struct Ent { uint32_t node; float t; };
+    struct Ent { uint32_t node; float t; int pushed_at; bool first; };
     std::vector<Ent> st; st.reserve(256);
     for (uint64_t r = 0; r < n; ++r) {
         f3 o = mk3(rays[r * 6], rays[r * 6 + 1], rays[r * 6 + 2]), d = mk3(rays[r * 6 + 3], rays[r * 6 + 4], rays[r * 6 + 5]);
@@ -84,7 +86,7 @@ void tlab_trace(void *h, const float *rays, uint64_t n, float t_min, float t_max
         float best = t_max; uint32_t bi = 0xFFFFFFFFu, bp = 0xFFFFFFFFu; bool hit = false;
         out[0]++;
         st.clear();
-        if (!bvh.nodes.empty() && !(oct & kRayDegenerate)) st.push_back({0u, t_min});
+        if (!bvh.nodes.empty() && !(oct & kRayDegenerate)) st.push_back({0u, t_min, 0, true});
         const uint32_t octinv = oct & 7u;
         struct Pend { uint32_t tri; int due; };
         std::vector<Pend> pend;
@@ -106,7 +108,7 @@ void tlab_trace(void *h, const float *rays, uint64_t n, float t_min, float t_max
             run_tests(false);
             Ent e = st.back(); st.pop_back();
             ++visit;
-            if (cull && e.t > best) continue;
+            if (cull && e.t > best) { if (e.first && e.pushed_at == visit) g_cull_first++; else g_cull_later++; continue; }
             const Bvh8Node &nd = bvh.nodes[e.node];
             out[2]++;
             float t_frame = t_min;
@@ -157,7 +159,7 @@ void tlab_trace(void *h, const float *rays, uint64_t n, float t_min, float t_max
             for (int k = 0; k < ni; ++k) {
                 int s = inner[k].s;
                 float tt = cull == 2 ? t_frame : cull == 4 ? t_all : cull == 5 ? (k + 1 < ni ? t_rest : t_min) : inner[k].t;
-                st.push_back({nd.child_base + bq_popc(nd.imask & ((1u << s) - 1u)), tt});
+                st.push_back({nd.child_base + bq_popc(nd.imask & ((1u << s) - 1u)), tt, visit, k + 1 == ni});
             }
         }
         if (hit) out[1]++;

@@ -60,6 +60,14 @@ for delay in (0, 1, 2, 4):
         o = (C.c_uint64 * 4)()
         L.tlab_trace(T, rays.ctypes.data, len(rays), 1e-3, 1e4, 0, 0, 0, o)
         print("%-8s triangle tests %d node visits after the leaf hit: nodes/ray %6.2f tris/ray %5.2f" % (label, delay, o[2] / o[0], o[3] / o[0]))
+for delay in (1, 2):
+    L.tlab_set_delay(delay)
+    for label, rays in (("bounce", bounce), ("primary", prim)):
+        for cull in (0, 1, 5, 4):
+            o = (C.c_uint64 * 4)()
+            L.tlab_trace(T, rays.ctypes.data, len(rays), 1e-3, 1e4, 0, 0, cull, o)
+            cc = (C.c_uint64 * 2)(); L.tlab_cull_counts(cc)
+            print("%-8s delay %d, octant order, per-child stale culling %d: nodes/ray %6.2f tris/ray %5.2f  culled/ray: first child %.2f, later pops %.2f" % (label, delay, cull, o[2] / o[0], o[3] / o[0], cc[0] / o[0], cc[1] / o[0]))
 L.tlab_set_delay(0)
 for label, rays in (("bounce", bounce), ("primary", prim)):
     for boxes, order, cull, what in ((0, 0, 0, "product: 8-bit planes, octant order"), (0, 1, 0, "8-bit, distance order"), (0, 0, 1, "8-bit, octant order, stale culling"),
