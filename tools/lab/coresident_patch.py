@@ -1,3 +1,8 @@
+"""Developer experiment, kept for the record (profiles/r02_coresident_shading.json): the source patch that
+ran the shading stage beside the other chunk's traversal kernel (64-VGPR / 256-thread build of k_shade, 7/8 traversal grid,
+PTX_CORESIDENT=k).  It applies to the tree at commit f6afedd (before k_shade's tile loop was software-pipelined), not to HEAD:
+    git stash; git checkout f6afedd -- path_tracer_amd/csrc; python tools/lab/coresident_patch.py [ntrec]; python -m path_tracer_amd.build
+"""
 import sys
 NT_REC = len(sys.argv) > 1 and sys.argv[1] == "ntrec"
 p='/root/repo/path_tracer_amd/csrc/ptx_kernels.hip'
