@@ -111,9 +111,12 @@ typedef struct {
     uint32_t normal_texture;      /* glTF normalTexture as bindless index + 1 (0: none), a LINEAR texture: tangent-space
                                      normal = texel x 2 - 1, +Y up; the tangent frame is derived per triangle from its
                                      world-space positions and uvs (the vertex format has no tangent); scale taken as 1 */
-    uint32_t emissive_texture;    /* glTF emissiveTexture as bindless index + 1 (0: none), an sRGB texture: emitted
-                                     radiance = emissive x texel at the point's uv -- at a hit and at a light sample; the
-                                     light table still picks triangles by area x luminance(emissive) (lit integrator only) */
+    uint32_t emissive_texture;    /* glTF emissiveTexture as bindless index + 1 (0: none): emitted radiance = emissive x texel
+                                     at the point's uv -- at a hit and at a light sample; the light table still picks
+                                     triangles by area x luminance(emissive) (lit integrator only).  The texel is decoded the
+                                     way the texture was registered (its PTX_TEXTURE_SRGB bit; the oracle does the same):
+                                     glTF defines emissive maps as sRGB, so hosts add them with the bit set, as both
+                                     loaders here do -- a map added without it is read as linear data, not rejected */
 } ptx_material_ext;
 
 typedef enum {
@@ -235,8 +238,12 @@ int ptx_render_batch(ptx_context *ctx, const ptx_uniforms *uniforms, const ptx_c
  * hipFree / stream or event creation and no host allocation.  Limits: width x height <= 262 144 pixels (512 x 512),
  * PTX_INTEGRATOR_REFERENCE only; beyond that it returns PTX_ERR_CAPACITY / PTX_ERR_INVALID with a message.  Every GPU
  * the library runs on holds its copy of the array (31.59 MB) until the process ends.  All contexts of one GPU share
- * that GPU's array: calls that overlap on one GPU (two contexts, two threads) race -- serialise them.  Ordered with
- * the context's other render calls; asynchronous on the context's main stream. */
+ * that GPU's array.  Calls issued one after the other -- from one host thread, or from several with the calls
+ * themselves serialised -- are ordered on the device too, across contexts (each static frame waits for the device's
+ * previous one through a per-device event), so no ptx_synchronize is needed between them; calls ISSUED concurrently
+ * from two threads on one GPU race.  Ordered with the context's other render calls; asynchronous on the context's main
+ * stream.  Note for callers under graph capture: the first launch of a kernel on a stream lets the HIP runtime size
+ * its private-segment (scratch) memory -- issue one warm-up frame before capturing. */
 int ptx_render_static(ptx_context *ctx, const ptx_uniforms *uniforms, const ptx_camera *camera,
                       const ptx_render_params *params);
 
@@ -257,6 +264,27 @@ int ptx_import_albedo_device(ptx_context *ctx, const void *device_src, uint64_t 
 /* Single-process hosts: sum the accumulation buffers of n contexts (one per GPU) into
  * ctxs[root] with an RCCL reduce over xGMI, then scale by 1/n. */
 int ptx_reduce_accumulation(ptx_context **ctxs, int n, int root);
+
+/* Build extension, no counterpart in the reference (its constants are compiled in, SURVEY.md 5 "config / flags"):
+ * per-context scheduling knobs.  None of them changes a result bit.  Each has an environment variable that only sets
+ * the DEFAULT of contexts created afterwards (named beside it), so two contexts of one process can differ and a host
+ * never has to touch the environment.  Values out of range return PTX_ERR_INVALID. */
+typedef enum {
+    PTX_OPTION_FRAMES_IN_FLIGHT = 1,   /* 1 .. 4 chunks (frames, or chunks of a batch) overlapping on as many streams; 2   [PTX_FRAMES_IN_FLIGHT] */
+    PTX_OPTION_TAIL_RAYS = 2,          /* expected queue length at or below which the remaining bounces of a chunk run as one
+                                          fused launch; 0: never; 65536                                                    [PTX_TAIL_RAYS] */
+    PTX_OPTION_TAIL_SHIFT = 3,         /* ... or at or below chunk paths >> shift; 7                                       [PTX_TAIL_SHIFT] */
+    PTX_OPTION_TARGET_PATHS = 4,       /* paths per chunk of a batch (48 + 24 B of queue state each, per frame in flight);
+                                          33 554 432                                                                       [PTX_TARGET_PATHS] */
+    PTX_OPTION_MATERIAL_SORT = 5,      /* lit integrator: group each bounce's queue by material class before shading
+                                          (measured 30 - 49 % slower); 0                              [PTX_MATERIAL_SORT] */
+    PTX_OPTION_EXTEND_WAVES = 6,       /* waves of the persistent traversal grid; 0 = what the device holds (default)      [PTX_EXTEND_WAVES] */
+    PTX_OPTION_SHADE_GRID = 7,         /* most blocks a shading launch starts; 0 = library default, 8192                   [PTX_SHADE_GRID] */
+    PTX_OPTION_HOST_REFIT = 8,         /* 1: ptx_update_instances never refits on the device; 0                            [PTX_HOST_REFIT] */
+    PTX_OPTION_REFIT_VERIFY = 9        /* 1: every device refit is compared with a host refit (tests); 0                   [PTX_REFIT_VERIFY] */
+} ptx_option;
+int ptx_set_option(ptx_context *ctx, int key, uint64_t value);
+int ptx_get_option(ptx_context *ctx, int key, uint64_t *value);
 
 int ptx_synchronize(ptx_context *ctx);
 int ptx_set_profiling(ptx_context *ctx, int level);     /* 0 off; 1 HIP-event timing of each stage launch (chunks still overlap on two streams, so a stage's

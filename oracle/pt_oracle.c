@@ -1184,10 +1184,23 @@ void orc_render(const orc_scene *s, const orc_camera *cam, const orc_uniforms *u
                 float *albedo, float *normal, float *depth, uint32_t *primary_ids,
                 orc_stats *stats, int n_threads)
 {
+    orc_render_rows(s, cam, u, p, width, height, 0, height, n_samples, albedo, normal, depth, primary_ids, stats, n_threads);
+}
+
+/* Rows [row_begin, row_end) of the same frames: a pixel's value depends on nothing but its own launch id
+ * (rgen.glsl:20-141 has no neighbourhood), so a band of a large frame equals the same rows of the full render.
+ * The image pointers are those of the FULL W x H images; rows outside the band are left untouched. */
+void orc_render_rows(const orc_scene *s, const orc_camera *cam, const orc_uniforms *u,
+                     const orc_params *p, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end,
+                     uint32_t n_samples, float *albedo, float *normal, float *depth, uint32_t *primary_ids,
+                     orc_stats *stats, int n_threads)
+{
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
+    if (row_end > height) row_end = height;
+    if (row_begin > row_end) row_begin = row_end;
     /* interleaved row bands keep threads balanced (sky rows are cheap) */
-    uint32_t band = 4, n_bands = (height + band - 1) / band;
+    uint32_t band = 4, n_bands = (row_end - row_begin + band - 1) / band;
     orc_stats total; memset(&total, 0, sizeof total);
     for (uint32_t f = 0; f < n_samples; ++f) {
         pthread_t th[256]; job_t *jobs = (job_t *)calloc(n_bands, sizeof(job_t));
@@ -1196,7 +1209,7 @@ void orc_render(const orc_scene *s, const orc_camera *cam, const orc_uniforms *u
             j->s = s; j->cam = cam; j->u = *u; j->p = *p; j->W = width; j->H = height;
             j->acc = u->accumulated_count + f;
             j->albedo = albedo; j->normal = normal; j->depth = depth; j->ids = primary_ids;
-            j->y0 = b * band; j->y1 = (b + 1) * band < height ? (b + 1) * band : height;
+            j->y0 = row_begin + b * band; j->y1 = j->y0 + band < row_end ? j->y0 + band : row_end;
         }
         band_arg *ta = (band_arg *)calloc((size_t)n_threads, sizeof(band_arg));
         for (int t = 0; t < n_threads; ++t) {

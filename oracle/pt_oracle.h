@@ -158,6 +158,13 @@ void orc_render(const orc_scene *s, const orc_camera *cam, const orc_uniforms *u
                 float *albedo, float *normal, float *depth, uint32_t *primary_ids,
                 orc_stats *stats, int n_threads);
 
+/* Rows [row_begin, row_end) of the same frames (image pointers are those of the full W x H images;
+ * the other rows are left untouched): a pixel depends only on its own launch id. */
+void orc_render_rows(const orc_scene *s, const orc_camera *cam, const orc_uniforms *u,
+                     const orc_params *p, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end,
+                     uint32_t n_samples, float *albedo, float *normal, float *depth, uint32_t *primary_ids,
+                     orc_stats *stats, int n_threads);
+
 /* lit integrator: number of emissive triangles in the light table, and row i of it
  * (9 floats of world-space vertices, 3 of radiance, cdf, pdf per unit area) for the tests */
 uint64_t orc_scene_light_count(const orc_scene *s);

@@ -78,6 +78,9 @@ def lib():
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Uniforms), C.POINTER(Params),
                                  C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.POINTER(Stats), C.c_int]
+        L.orc_render_rows.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Uniforms), C.POINTER(Params),
+                                      C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_int]
         L.orc_scene_light_count.restype = C.c_uint64
         L.orc_scene_light_count.argtypes = [C.c_void_p]
         L.orc_scene_light.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_float),
@@ -171,8 +174,10 @@ class OracleScene:
         return lib().orc_scene_triangle_count(self.handle)
 
     def render(self, cam, width, height, n_samples, seed, first_sample=0, z_near=0.1, z_far=100.0, params=None,
-               albedo=None, threads=None, want_ids=True):
-        """Returns dict(albedo HxWx4 f32, normal HxWx4, depth HxW, ids HxWx2 u32, stats)."""
+               albedo=None, threads=None, want_ids=True, rows=None):
+        """Returns dict(albedo HxWx4 f32, normal HxWx4, depth HxW, ids HxWx2 u32, stats).
+        rows=(y0, y1): only that band of the frame is rendered (the images keep the full extent; the other rows stay
+        as initialised) -- a pixel depends on nothing but its own launch id, so the band equals the full render's rows."""
         params = params or default_params()
         u = Uniforms(1, seed, first_sample, z_near, z_far, (C.c_uint32 * 3)(0, 0, 0))
         if albedo is None:
@@ -182,9 +187,10 @@ class OracleScene:
         ids = np.full((height, width, 2), 0xFFFFFFFF, dtype=np.uint32) if want_ids else None
         st = Stats()
         threads = threads or min(os.cpu_count() or 1, 16)
-        lib().orc_render(self.handle, C.byref(cam), C.byref(u), C.byref(params), width, height, n_samples,
-                         albedo.ctypes.data, normal.ctypes.data, depth.ctypes.data,
-                         ids.ctypes.data if ids is not None else None, C.byref(st), threads)
+        y0, y1 = rows if rows is not None else (0, height)
+        lib().orc_render_rows(self.handle, C.byref(cam), C.byref(u), C.byref(params), width, height, y0, y1, n_samples,
+                              albedo.ctypes.data, normal.ctypes.data, depth.ctypes.data,
+                              ids.ctypes.data if ids is not None else None, C.byref(st), threads)
         return dict(albedo=albedo, normal=normal, depth=depth, ids=ids,
                     stats={k: getattr(st, k) for k, _ in Stats._fields_})
 

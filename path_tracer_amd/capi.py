@@ -79,7 +79,11 @@ EXPORTS = [
     "ptx_export_albedo_device", "ptx_import_albedo_device", "ptx_reduce_accumulation", "ptx_synchronize",
     "ptx_set_profiling", "ptx_get_stats", "ptx_reset_stats", "ptx_last_error",
     "ptx_set_material_ext", "ptx_set_scene_options", "ptx_update_instances", "ptx_render_static",
+    "ptx_set_option", "ptx_get_option",
 ]
+# ptx_option (include/ptx.h)
+(OPTION_FRAMES_IN_FLIGHT, OPTION_TAIL_RAYS, OPTION_TAIL_SHIFT, OPTION_TARGET_PATHS, OPTION_MATERIAL_SORT,
+ OPTION_EXTEND_WAVES, OPTION_SHADE_GRID, OPTION_HOST_REFIT, OPTION_REFIT_VERIFY) = range(1, 10)
 
 _lib = None
 
@@ -131,6 +135,8 @@ def load():
     L.ptx_last_error.restype = C.c_char_p
     L.ptx_set_material_ext.argtypes = [vp, C.c_uint32, vp]
     L.ptx_set_scene_options.argtypes = [vp, C.c_uint32]
+    L.ptx_set_option.argtypes = [vp, C.c_int, C.c_uint64]
+    L.ptx_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -209,6 +215,14 @@ class Context:
 
     def set_scene_options(self, options):
         self._check(self._L.ptx_set_scene_options(self.handle, options))
+
+    def set_option(self, key, value):
+        self._check(self._L.ptx_set_option(self.handle, int(key), int(value)))
+
+    def get_option(self, key):
+        out = C.c_uint64()
+        self._check(self._L.ptx_get_option(self.handle, int(key), C.byref(out)))
+        return out.value
 
     def create_geometry(self, first_vertex, n_vertices, first_index, n_indices):
         out = C.c_uint32()

@@ -72,6 +72,11 @@ static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mutex;
 void *g_scratch_ptr[kMaxDevices] = {};      // device address of `scratch` on each device, looked up on first use
+// Recorded behind every ptx_render_static frame of the device, whatever the context: the next static frame on that device
+// -- any context, any stream -- waits for it before it touches the shared array, so back-to-back calls from one host
+// thread on different contexts of one GPU are ordered on the device, not just on the host.  Created with the address
+// (set-up time), so the render call itself still creates nothing.
+hipEvent_t g_scratch_event[kMaxDevices] = {};
 
 // `device` must be the current device.  Returns NULL (and the HIP error in `err`) if the symbol cannot be resolved.
 void *static_scratch_for(int device, hipError_t &err)
@@ -83,6 +88,10 @@ void *static_scratch_for(int device, hipError_t &err)
         void *p = nullptr;
         err = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
         if (err != hipSuccess || !p) { if (err == hipSuccess) err = hipErrorInvalidSymbol; return nullptr; }
+        hipEvent_t ev = nullptr;
+        err = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (err != hipSuccess) return nullptr;
+        g_scratch_event[device] = ev;
         g_scratch_ptr[device] = p;
     }
     return g_scratch_ptr[device];
@@ -148,6 +157,9 @@ struct ptx_context {
     uint32_t frac_bounces = 0;
     float live_frac[kMaxDepthLimit] = {};
     uint32_t tail_shift = 7;                // ... or below 1/128 of the chunk's paths (PTX_TAIL_SHIFT): big batches hand over earlier
+    uint32_t shade_grid = 0;                // most blocks of a shading launch (PTX_OPTION_SHADE_GRID); 0: the library default (8192)
+    bool host_refit_only = false;           // PTX_OPTION_HOST_REFIT: instance motion never takes the device refit
+    bool refit_verify = false;              // PTX_OPTION_REFIT_VERIFY: every device refit is checked against a host refit (tests)
     bool material_sort = false;             // PTX_MATERIAL_SORT=1: the lit integrator groups each bounce's queue by material class before shading (measured option)
     uint32_t tail_rays = 65536;             // PTX_TAIL_RAYS: expected queue length at or below which the tail takes over; 0: never
     hipEvent_t last_resolved = nullptr;     // = sets[k].resolved of the most recent chunk: the next resolve waits for it
@@ -425,6 +437,8 @@ int ptx_create_with_limits(int device_ordinal, const ptx_limits *limits, ptx_con
     if (const char *tr = getenv("PTX_TAIL_RAYS")) { long v = strtol(tr, nullptr, 10); if (v >= 0) c->tail_rays = (uint32_t)std::min<long>(v, 1 << 24); }
     if (const char *ms = getenv("PTX_MATERIAL_SORT")) c->material_sort = atoi(ms) != 0;
     if (const char *fi = getenv("PTX_FRAMES_IN_FLIGHT")) { long v = strtol(fi, nullptr, 10); if (v >= 1 && v <= kMaxSets) c->n_sets = (int)v; }
+    c->host_refit_only = getenv("PTX_HOST_REFIT") != nullptr;
+    c->refit_verify = getenv("PTX_REFIT_VERIFY") != nullptr;
     CREATE_TRY(hipMalloc((void **)&c->d_totals, kNumTotals * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->d_totals, 0, kNumTotals * sizeof(uint64_t)));
     CREATE_TRY(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
@@ -620,7 +634,7 @@ static int device_refit(ptx_context *c, const ptx_instance *inst, uint32_t n, bo
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     double sah = st.root_area > 0.0 ? st.area_sum / st.root_area : 0.0;
     if (st.non_finite || !(sah <= c->built_sah * kRefitSahLimit)) return PTX_OK;
-    if (getenv("PTX_REFIT_VERIFY")) {
+    if (c->refit_verify) {
         // developer / test check: the host refit of the same motion must give byte-identical nodes and triangles
         uint64_t n_tris = 0;
         for (uint32_t i = 0; i < n; ++i) n_tris += c->geometries[inst[i].geometry].n_indices / 3;
@@ -695,7 +709,7 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
     for (uint32_t i = 0; i < n && same_list; ++i)
         same_list = inst[i].geometry == c->built_instances[i].geometry && memcmp(&inst[i].off, &c->built_instances[i].off, sizeof(ptx_offsets)) == 0;
     // on the device when nothing else has to change (an emitter that moves takes the light table with it: host path)
-    const bool host_refit_only = getenv("PTX_HOST_REFIT") != nullptr;
+    const bool host_refit_only = c->host_refit_only;
     bool emitter_moved = false;
     if (same_list && c->n_lights)
         for (uint32_t i = 0; i < n && !emitter_moved; ++i) {
@@ -975,6 +989,8 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
     ptx_render_params p;
     if (pp) p = *pp; else ptx_default_params(&p);
     if (p.max_depth > kMaxDepthLimit) return fail(c, PTX_ERR_INVALID, "ptx_render: max_depth above 64");
+    // the traversal orders hits by the bit pattern of t and tests boxes in t_min-shifted time: both need 0 <= t_min < t_max
+    if (!(p.t_min >= 0.0f) || !(p.t_max > p.t_min)) return fail(c, PTX_ERR_INVALID, "ptx_render: needs 0 <= t_min < t_max");
     if (p.integrator != PTX_INTEGRATOR_REFERENCE && p.integrator != PTX_INTEGRATOR_LIT)
         return fail(c, PTX_ERR_INVALID, "ptx_render: unknown integrator");
     const bool lit = p.integrator == PTX_INTEGRATOR_LIT;
@@ -1061,14 +1077,14 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
                 HIP_TRY(c, hipStreamWaitEvent(st, c->last_first_shade, 0));
             e2.begin(c, 1, st);
             if (!lit) {
-                launch_shade(st, sc, f, img, b, rin, ps.d_hits, ps.d_counters, n_paths, rout, ps.d_results);
+                launch_shade(st, sc, f, img, b, rin, ps.d_hits, ps.d_counters, n_paths, rout, ps.d_results, c->shade_grid);
             } else {
                 const uint32_t *order = nullptr;
                 if (c->material_sort) {
-                    launch_material_sort(st, sc, ps.d_hits, ps.d_counters + b, n_paths, ps.d_class_count, ps.d_order);
+                    launch_material_sort(st, sc, ps.d_hits, ps.d_counters + b, n_paths, ps.d_class_count, ps.d_order, c->shade_grid);
                     order = ps.d_order;
                 }
-                launch_shade_lit(st, sc, f, img, b, rin, ps.d_hits, ps.d_counters, n_paths, rout, shadow_q, ps.d_results, order);
+                launch_shade_lit(st, sc, f, img, b, rin, ps.d_hits, ps.d_counters, n_paths, rout, shadow_q, ps.d_results, order, c->shade_grid);
             }
             if (b == 0) { HIP_TRY(c, hipEventRecord(ps.first_shade, st)); c->last_first_shade = ps.first_shade; }
             e2.end(st);
@@ -1079,7 +1095,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
                 launch_extend(st, sc, f, shadow_q, ps.d_counters + kShadowCount + b, ps.d_counters + fetch_heads(b, 1), n_paths,
                               waves, ps.d_hits, nullptr, true);
                 e3.end(st);
-                launch_shadow_resolve(st, b, shadow_q, ps.d_hits, ps.d_counters, n_paths, ps.d_results);
+                launch_shadow_resolve(st, b, shadow_q, ps.d_hits, ps.d_counters, n_paths, ps.d_results, c->shade_grid);
             }
         }
         // samples join the running mean in accumulated_count order: this chunk's resolve after the previous chunk's
@@ -1117,6 +1133,7 @@ int ptx_render_static(ptx_context *c, const ptx_uniforms *u, const ptx_camera *c
     ptx_render_params p;
     if (pp) p = *pp; else ptx_default_params(&p);
     if (p.max_depth > kMaxDepthLimit) return fail(c, PTX_ERR_INVALID, "ptx_render_static: max_depth above 64");
+    if (!(p.t_min >= 0.0f) || !(p.t_max > p.t_min)) return fail(c, PTX_ERR_INVALID, "ptx_render_static: needs 0 <= t_min < t_max");
     if (p.integrator != PTX_INTEGRATOR_REFERENCE)
         return fail(c, PTX_ERR_INVALID, "ptx_render_static: only PTX_INTEGRATOR_REFERENCE (the lit integrator's occlusion queue is not part of the static scratch)");
     const uint64_t npix = (uint64_t)c->width * c->height;
@@ -1156,17 +1173,21 @@ int ptx_render_static(ptx_context *c, const ptx_uniforms *u, const ptx_camera *c
     // behind the chunks already in flight on the path sets: their G-buffer writes and their resolves
     if (c->last_first_shade && c->last_first_shade != c->static_done) HIP_TRY(c, hipStreamWaitEvent(st, c->last_first_shade, 0));
     if (c->last_resolved && c->last_resolved != c->static_done) HIP_TRY(c, hipStreamWaitEvent(st, c->last_resolved, 0));
+    // behind the latest static frame of ANY context on this device: they all share the one scratch array
+    hipEvent_t dev_ev = (c->device >= 0 && c->device < kMaxDevices) ? g_scratch_event[c->device] : nullptr;
+    if (dev_ev) HIP_TRY(c, hipStreamWaitEvent(st, dev_ev, 0));
     // k_raygen's first block clears every counter and fetch head the frame uses: nothing is kept from the last call
     launch_raygen(st, f, n_paths, make_ray_queue(rays[0], kStaticMaxPaths), counters);
     for (uint32_t b = 0; b < bounces; ++b) {
         RayQueue rin = make_ray_queue(rays[b & 1], kStaticMaxPaths), rout = make_ray_queue(rays[(b & 1) ^ 1], kStaticMaxPaths);
         launch_extend(st, sc, f, rin, counters + b, counters + fetch_heads(b, 0), n_paths, c->extend_waves, hits, nullptr, false, b == 0);
-        launch_shade(st, sc, f, img, b, rin, hits, counters, n_paths, rout, results);
+        launch_shade(st, sc, f, img, b, rin, hits, counters, n_paths, rout, results, c->shade_grid);
     }
     launch_resolve(st, f, img, results, 1);
     launch_accumulate_stats(st, counters, bounces, (uint64_t)n_paths, c->d_totals);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->static_done, st));
+    if (dev_ev) HIP_TRY(c, hipEventRecord(dev_ev, st));
     c->last_resolved = c->static_done;
     c->last_first_shade = c->static_done;
     return PTX_OK;
@@ -1235,6 +1256,66 @@ int ptx_import_albedo_device(ptx_context *c, const void *device_src, uint64_t by
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return PTX_OK;
+}
+
+// Build extension: per-context tuning knobs (each has an environment variable of the same meaning that only sets the
+// DEFAULT of contexts created afterwards).  None of them changes a result bit: they steer scheduling only.
+int ptx_set_option(ptx_context *c, int key, uint64_t value)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    switch (key) {
+    case PTX_OPTION_FRAMES_IN_FLIGHT:
+        if (value < 1 || value > (uint64_t)kMaxSets) return fail(c, PTX_ERR_INVALID, "ptx_set_option: frames in flight must be 1 .. 4");
+        if (int r = sync_all(c)) return r;          // chunks in flight keep their sets; the rotation restarts on set 0
+        c->n_sets = (int)value; c->next_set = 0;
+        return PTX_OK;
+    case PTX_OPTION_TAIL_RAYS:
+        c->tail_rays = (uint32_t)std::min<uint64_t>(value, 1u << 24);
+        return PTX_OK;
+    case PTX_OPTION_TAIL_SHIFT:
+        if (value > 31) return fail(c, PTX_ERR_INVALID, "ptx_set_option: tail shift must be 0 .. 31");
+        c->tail_shift = (uint32_t)value;
+        return PTX_OK;
+    case PTX_OPTION_TARGET_PATHS:
+        if (value < 4096 || value > 0xFFFFFF00ull) return fail(c, PTX_ERR_INVALID, "ptx_set_option: paths per chunk must be 4096 .. 2^32 - 256");
+        c->target_paths = value;
+        return PTX_OK;
+    case PTX_OPTION_MATERIAL_SORT:
+        if (value > 1) return fail(c, PTX_ERR_INVALID, "ptx_set_option: material sort is 0 or 1");
+        if (int r = sync_all(c)) return r;
+        c->material_sort = value != 0;
+        return PTX_OK;
+    case PTX_OPTION_EXTEND_WAVES:
+        if (value > (1u << 20)) return fail(c, PTX_ERR_INVALID, "ptx_set_option: traversal grid above 2^20 waves");
+        c->extend_waves = value ? (uint32_t)value : extend_resident_waves(c->device);
+        return PTX_OK;
+    case PTX_OPTION_SHADE_GRID:
+        if (value > (1u << 24)) return fail(c, PTX_ERR_INVALID, "ptx_set_option: shading grid above 2^24 blocks");
+        c->shade_grid = (uint32_t)value;
+        return PTX_OK;
+    case PTX_OPTION_HOST_REFIT: c->host_refit_only = value != 0; return PTX_OK;
+    case PTX_OPTION_REFIT_VERIFY: c->refit_verify = value != 0; return PTX_OK;
+    default: return fail(c, PTX_ERR_INVALID, "ptx_set_option: unknown option key");
+    }
+}
+
+int ptx_get_option(ptx_context *c, int key, uint64_t *value)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (!value) return fail(c, PTX_ERR_INVALID, "ptx_get_option: NULL argument");
+    switch (key) {
+    case PTX_OPTION_FRAMES_IN_FLIGHT: *value = (uint64_t)c->n_sets; return PTX_OK;
+    case PTX_OPTION_TAIL_RAYS: *value = c->tail_rays; return PTX_OK;
+    case PTX_OPTION_TAIL_SHIFT: *value = c->tail_shift; return PTX_OK;
+    case PTX_OPTION_TARGET_PATHS: *value = c->target_paths; return PTX_OK;
+    case PTX_OPTION_MATERIAL_SORT: *value = c->material_sort ? 1 : 0; return PTX_OK;
+    case PTX_OPTION_EXTEND_WAVES: *value = c->extend_waves; return PTX_OK;
+    case PTX_OPTION_SHADE_GRID: *value = c->shade_grid ? c->shade_grid : default_shade_grid(); return PTX_OK;
+    case PTX_OPTION_HOST_REFIT: *value = c->host_refit_only ? 1 : 0; return PTX_OK;
+    case PTX_OPTION_REFIT_VERIFY: *value = c->refit_verify ? 1 : 0; return PTX_OK;
+    default: return fail(c, PTX_ERR_INVALID, "ptx_get_option: unknown option key");
+    }
 }
 
 int ptx_synchronize(ptx_context *c)

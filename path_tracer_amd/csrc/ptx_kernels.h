@@ -152,19 +152,21 @@ void launch_tail_lit(hipStream_t s, const SceneDev &sc, const FrameDev &f, uint3
                      uint32_t capacity, float4 *results);
 void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
                   RayQueue rays_in, const HitOut *hits, uint32_t *counters, uint32_t capacity, RayQueue rays_out,
-                  float4 *results);
+                  float4 *results, uint32_t grid_cap = 0 /* most blocks the launch starts; 0: the default (PTX_SHADE_GRID, 8192) */);
 // Lit integrator: shading with next-event estimation.  Survivors go to rays_out, occlusion rays to
 // `shadow` (count in counters[kShadowCount + depth]); radiance is accumulated in results[path].
 void launch_shade_lit(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
                       RayQueue rays_in, const HitOut *hits, uint32_t *counters, uint32_t capacity, RayQueue rays_out,
-                      RayQueue shadow, float4 *results, const uint32_t *order = nullptr /* k_material_sort's permutation */);
+                      RayQueue shadow, float4 *results, const uint32_t *order = nullptr /* k_material_sort's permutation */,
+                      uint32_t grid_cap = 0);
 // Material sorting option of the lit integrator: order[0 .. *count) = the queue positions grouped by the material class of
 // their hit (sky, opaque, transmissive); class_count: 6 words of scratch
 void launch_material_sort(hipStream_t s, const SceneDev &sc, const HitOut *hits, const uint32_t *count, uint32_t capacity,
-                          uint32_t *class_count, uint32_t *order);
+                          uint32_t *class_count, uint32_t *order, uint32_t grid_cap = 0);
 // adds the contribution of every unoccluded occlusion ray of bounce `depth` to its path's radiance
 void launch_shadow_resolve(hipStream_t s, uint32_t depth, RayQueue shadow, const HitOut *hits, const uint32_t *counters,
-                           uint32_t capacity, float4 *results);
+                           uint32_t capacity, float4 *results, uint32_t grid_cap = 0);
+uint32_t default_shade_grid();      // PTX_SHADE_GRID or 8192
 void launch_resolve(hipStream_t s, const FrameDev &f, const ImagesDev &img, const float4 *results, uint32_t n_samples);
 void launch_accumulate_stats(hipStream_t s, const uint32_t *counters, uint32_t max_depth, uint64_t n_samples,
                              uint64_t *totals);

@@ -1445,20 +1445,22 @@ uint32_t extend_resident_waves(int device)
     return (uint32_t)per_cu * (uint32_t)cus;
 }
 
-// most blocks a shading launch starts; a block walks tiles beyond that (PTX_SHADE_GRID)
-static uint32_t shade_grid_cap()
+// most blocks a shading launch starts; a block walks tiles beyond that (ptx_set_option PTX_OPTION_SHADE_GRID; the
+// environment variable PTX_SHADE_GRID only sets the default of new contexts)
+uint32_t default_shade_grid()
 {
     static const uint32_t cap = [] { const char *e = getenv("PTX_SHADE_GRID"); int v = e ? atoi(e) : 8192; return (uint32_t)(v < 64 ? 64 : v); }();
     return cap;
 }
+static uint32_t shade_grid_cap(uint32_t grid_cap) { return grid_cap ? (grid_cap < 64u ? 64u : grid_cap) : default_shade_grid(); }
 
 void launch_shade(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
                   RayQueue rays_in, const HitOut *hits, uint32_t *counters, uint32_t capacity, RayQueue rays_out,
-                  float4 *results)
+                  float4 *results, uint32_t grid_cap)
 {
     uint32_t blocks = (capacity + kShadeBlock - 1u) / kShadeBlock;
     if (!blocks) return;
-    blocks = std::min(blocks, shade_grid_cap());
+    blocks = std::min(blocks, shade_grid_cap(grid_cap));
     hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(kShadeBlock), 0, s, sc, f, img, depth, rays_in, hits, counters,
                        capacity, rays_out, results);
 }
@@ -1481,32 +1483,32 @@ void launch_tail_lit(hipStream_t s, const SceneDev &sc, const FrameDev &f, uint3
 
 void launch_shade_lit(hipStream_t s, const SceneDev &sc, const FrameDev &f, const ImagesDev &img, uint32_t depth,
                       RayQueue rays_in, const HitOut *hits, uint32_t *counters, uint32_t capacity, RayQueue rays_out,
-                      RayQueue shadow, float4 *results, const uint32_t *order)
+                      RayQueue shadow, float4 *results, const uint32_t *order, uint32_t grid_cap)
 {
     uint32_t blocks = (capacity + kShadeBlock - 1u) / kShadeBlock;
     if (!blocks) return;
-    blocks = std::min(blocks, shade_grid_cap());
+    blocks = std::min(blocks, shade_grid_cap(grid_cap));
     hipLaunchKernelGGL(k_shade_lit, dim3(blocks), dim3(kShadeBlock), 0, s, sc, f, img, depth, rays_in, hits, counters,
                        capacity, rays_out, shadow, results, order);
 }
 
 void launch_material_sort(hipStream_t s, const SceneDev &sc, const HitOut *hits, const uint32_t *count, uint32_t capacity,
-                          uint32_t *class_count, uint32_t *order)
+                          uint32_t *class_count, uint32_t *order, uint32_t grid_cap)
 {
     uint32_t blocks = (capacity + kShadeBlock - 1u) / kShadeBlock;
     if (!blocks) return;
-    blocks = std::min(blocks, shade_grid_cap());
+    blocks = std::min(blocks, shade_grid_cap(grid_cap));
     (void)hipMemsetAsync(class_count, 0, 2 * kSortClasses * sizeof(uint32_t), s);
     hipLaunchKernelGGL((k_material_sort<true>), dim3(blocks), dim3(kShadeBlock), 0, s, sc, hits, count, class_count, order);
     hipLaunchKernelGGL((k_material_sort<false>), dim3(blocks), dim3(kShadeBlock), 0, s, sc, hits, count, class_count, order);
 }
 
 void launch_shadow_resolve(hipStream_t s, uint32_t depth, RayQueue shadow, const HitOut *hits, const uint32_t *counters,
-                           uint32_t capacity, float4 *results)
+                           uint32_t capacity, float4 *results, uint32_t grid_cap)
 {
     uint32_t blocks = (capacity + 255u) / 256u;
     if (!blocks) return;
-    blocks = std::min(blocks, shade_grid_cap() * 2u);
+    blocks = std::min(blocks, shade_grid_cap(grid_cap) * 2u);
     hipLaunchKernelGGL(k_shadow_resolve, dim3(blocks), dim3(256), 0, s, depth, shadow, hits, counters, results);
 }
 

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <cstdlib>
+
 #include <map>
 #include <mutex>
 #include <string>
@@ -37,6 +39,7 @@ struct RcclApi {
     fn_GroupEnd group_end = nullptr;
     fn_Reduce reduce = nullptr;
     fn_GetErrorString err_str = nullptr;
+    bool test_stub = false;         // the loaded library is tests/native/rccl_stub.cpp (exports ptx_rccl_test_stub)
     std::string load_error;
 };
 struct CommSet {
@@ -51,7 +54,11 @@ std::map<int, int> g_live_contexts; // device -> contexts alive on it
 bool load_api()
 {
     if (g_api.lib) return true;
-    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // PTX_RCCL_LIB: path of the collective library to load instead of the loader's librccl.so (a site build of RCCL; the
+    // call-recording stub of the test suite)
+    void *lib = nullptr;
+    if (const char *path = getenv("PTX_RCCL_LIB")) lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) { const char *e = dlerror(); g_api.load_error = std::string("cannot load librccl: ") + (e ? e : "?"); return false; }
     RcclApi a;
@@ -66,6 +73,7 @@ bool load_api()
         dlclose(lib);
         return false;
     }
+    a.test_stub = dlsym(lib, "ptx_rccl_test_stub") != nullptr;
     a.lib = lib;
     g_api = a;
     return true;
@@ -118,19 +126,25 @@ extern "C" int ptx_reduce_accumulation(ptx_context **ctxs, int n, int root)
         if (!ctxs[i]) return ptx::ctx_fail(rc, PTX_ERR_INVALID, "ptx_reduce_accumulation: NULL context");
         if (ptx::ctx_pixels(ctxs[i]) != np) return ptx::ctx_fail(rc, PTX_ERR_INVALID, "ptx_reduce_accumulation: image extents differ");
         devs[i] = ptx::ctx_device(ctxs[i]);
-        for (int j = 0; j < i; ++j)
-            if (devs[j] == devs[i]) return ptx::ctx_fail(rc, PTX_ERR_INVALID, "ptx_reduce_accumulation: two contexts on one device");
     }
+    bool shared_device = false;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j) shared_device = shared_device || devs[j] == devs[i];
     if (n == 1) return ptx_synchronize(rc);
 
+    // every return path below leaves the caller's current device as it was (ptx_synchronize binds each context's)
     int caller_device = 0;
     const bool have_caller_device = hipGetDevice(&caller_device) == hipSuccess;
+    auto leave = [&](int code) { if (have_caller_device) (void)hipSetDevice(caller_device); return code; };
     for (int i = 0; i < n; ++i)
-        if (int r = ptx_synchronize(ctxs[i])) return r;
+        if (int r = ptx_synchronize(ctxs[i])) return leave(r);
     int status = PTX_OK;
     {
         std::lock_guard<std::mutex> lock(g_mutex);
-        if (!load_api()) return ptx::ctx_fail(rc, PTX_ERR_HIP, "ptx_reduce_accumulation: " + g_api.load_error);
+        if (!load_api()) return leave(ptx::ctx_fail(rc, PTX_ERR_HIP, "ptx_reduce_accumulation: " + g_api.load_error));
+        // RCCL wants one rank per device; only the test suite's host-side stub can sum two buffers of one GPU
+        if (shared_device && !g_api.test_stub)
+            return leave(ptx::ctx_fail(rc, PTX_ERR_INVALID, "ptx_reduce_accumulation: two contexts on one device"));
         CommSet *cs = nullptr;
         for (CommSet &c : g_sets) if (c.devs == devs) cs = &c;
         if (!cs) {
@@ -140,8 +154,7 @@ extern "C" int ptx_reduce_accumulation(ptx_context **ctxs, int n, int root)
             int e = g_api.comm_init_all(fresh.comms.data(), n, devs.data());
             if (e) {
                 destroy_set(fresh);
-                if (have_caller_device) (void)hipSetDevice(caller_device);
-                return ptx::ctx_fail(rc, PTX_ERR_HIP, std::string("ncclCommInitAll: ") + (g_api.err_str ? g_api.err_str(e) : "error"));
+                return leave(ptx::ctx_fail(rc, PTX_ERR_HIP, std::string("ncclCommInitAll: ") + (g_api.err_str ? g_api.err_str(e) : "error")));
             }
             g_sets.push_back(fresh);
             cs = &g_sets.back();
@@ -158,6 +171,5 @@ extern "C" int ptx_reduce_accumulation(ptx_context **ctxs, int n, int root)
     for (int i = 0; i < n; ++i) (void)ptx_synchronize(ctxs[i]);
     // mean of the per-GPU means (each GPU rendered the same number of samples); alpha back to 1
     if (!status) status = ptx_import_albedo_device(rc, ptx::ctx_albedo(rc), np * 16, 1.0f / (float)n);
-    if (have_caller_device) (void)hipSetDevice(caller_device);
-    return status;
+    return leave(status);
 }

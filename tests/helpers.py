@@ -212,3 +212,18 @@ def write_mr_quad_gltf(dirpath, with_maps=False):
     path = os.path.join(dirpath, "mrquad.gltf")
     json.dump(doc, open(path, "w"))
     return path
+
+
+RCCL_STUB = os.path.join(ROOT, "tests", "native", "librccl_stub.so")
+
+
+def build_rccl_stub(force=False):
+    """tests/native/rccl_stub.cpp -> tests/native/librccl_stub.so (plain g++ against the HIP runtime API; built on the CPU
+    box by __graft_entry__.build(), travels to the GPU box with the tree)."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "native", "rccl_stub.cpp")
+    if not force and os.path.exists(RCCL_STUB) and os.path.getmtime(RCCL_STUB) >= os.path.getmtime(src):
+        return RCCL_STUB
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           src, "-o", RCCL_STUB, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    return RCCL_STUB

@@ -49,15 +49,56 @@ def test_c3_sponza_1080p_bit_exact_and_c5_4k_primary_ids(oracle, gpu_ctx_factory
     got = gpu_render(ctx, oracle, cam, 1920, 1080, 1)
     assert_images_bit_equal(got, want, "sponza 1920x1080x1")
     assert want["stats"]["textured_hits"] == want["stats"]["hits"] > 0
-    # C5: 3840x2160 -- size-independent properties instead of a full oracle image:
-    #  * the primary-hit ids of every even pixel centre ... do not coincide with 1080p centres, so check instead that
-    #  * 2 spp in one batch == 2 single renders (chunking at 8.3 M pixels), and a 64-row band matches the oracle exactly.
+    # C5: 3840x2160 -- the oracle needs minutes for the full frame, so:
+    #  * 2 spp in one batch == 2 single renders (chunking at 8.3 M pixels), and
+    #  * three row bands of the frame -- the top 16 rows, 64 rows through the middle of the atrium, the bottom 16 rows --
+    #    equal the oracle's render of the same rows bit for bit (a pixel depends on nothing but its own launch id,
+    #    rgen.glsl:20-141, so orc_render_rows of a band IS the full render's band).
     a = gpu_render(ctx, oracle, cam, 3840, 2160, 2, batch=True)
     b = gpu_render(ctx, oracle, cam, 3840, 2160, 2, batch=False)
     assert_images_bit_equal(a, b, "4K batch vs repeated")
     assert np.all(a["albedo"][..., 3] == 1.0) and np.isfinite(a["albedo"]).all()
     st = ctx.stats()
     assert st["samples"] >= 2 * 2 * 3840 * 2160
+    for y0, y1 in ((0, 16), (1048, 1112), (2144, 2160)):
+        band = sc.render(cam, 3840, 2160, 2, SEED, rows=(y0, y1))
+        assert band["stats"]["samples"] == 2 * 3840 * (y1 - y0)
+        assert_images_bit_equal({k: a[k][y0:y1] for k in ("ids", "normal", "depth", "albedo")},
+                                {k: band[k][y0:y1] for k in ("ids", "normal", "depth", "albedo")}, "4K rows %d..%d vs oracle" % (y0, y1))
+    mid = sc.render(cam, 3840, 2160, 1, SEED, rows=(1048, 1112))
+    assert (mid["ids"][1048:1112, :, 0] != 0xFFFFFFFF).mean() > 0.5          # the band really looks at geometry
+
+
+def test_c3_sponza_1080p_lit_nee_bit_exact(oracle, gpu_ctx_factory, standins_ready):
+    """BASELINE.json config 3 names next-event estimation: the lit integrator on the Sponza stand-in at 1920x1080 --
+    bench.py's `--integrator lit` workload (the emitters of bench.lit_emitters, the scene's real metallic-roughness and
+    normal maps, world normals, texel x factor, sampler wrap / filter modes) -- one sample per pixel through the C ABI
+    against oracle/pt_oracle.c raygen_pixel_lit: ids, normal, depth and RGBA32F radiance bitwise, and the ray, hit and
+    occlusion-ray counts."""
+    import bench
+    from path_tracer_amd import capi, host
+    ing = ingest(("sponza/Sponza.gltf", (0, 0, 0)), decode_image=host.decode_image, ref_quirks=False)
+    n_emit = 0
+    for row, ext in bench.lit_emitters("sponza_1080p", ing.materials):
+        ing.material_ext[row] = ext[0]
+        n_emit += 1
+    assert n_emit > 0
+    assert any(int(e["mr_texture"]) for e in ing.material_ext) and any(int(e["normal_texture"]) for e in ing.material_ext)
+    opts = capi.SCENE_WORLD_NORMALS | capi.SCENE_TEXTURE_TIMES_FACTOR
+    ctx = gpu_ctx_factory(limits=_big_limits())
+    upload(ctx, ing, oracle, options=opts, with_material_ext=True)
+    sc = oracle.scene_from_ingest(ing, options=oracle.SCENE_WORLD_NORMALS | oracle.SCENE_TEXTURE_TIMES_FACTOR, with_material_ext=True)
+    cam = oracle.camera_matrices([-8.0, 1.6, 0.0], oracle.yaw_quat(-90), np.deg2rad(np.float32(70)), 16 / 9, 0.1, 1000.0)
+    want = sc.render(cam, 1920, 1080, 1, SEED, params=oracle.default_params(integrator=oracle.INTEGRATOR_LIT))
+    ctx.reset_stats()
+    got = gpu_render(ctx, oracle, cam, 1920, 1080, 1, params=capi.default_params(integrator=capi.INTEGRATOR_LIT))
+    assert_images_bit_equal(got, want, "lit sponza 1920x1080x1")
+    st = ctx.stats()
+    assert st["lights"] == len(sc.lights()) > 1000
+    assert st["samples"] == want["stats"]["samples"] == 1920 * 1080
+    assert st["rays"] == want["stats"]["rays"] and st["hits"] == want["stats"]["hits"]
+    assert st["shadow_rays"] == want["stats"]["shadow_rays"] > 1920 * 1080 // 2
+    assert np.isfinite(got["albedo"]).all() and got["albedo"][..., :3].max() > 1.0
 
 
 def test_accumulation_resume_and_device_export(oracle, gpu_ctx_factory):
@@ -126,6 +167,13 @@ def test_error_paths(oracle, gpu_ctx_factory):
     assert e.value.code == capi.PTX_ERR_STATE                        # no image yet
     ctx.resize(16, 16)
     ctx.render(u, cam)
+    # the traversal orders hits by the bits of t and tests boxes in t_min-shifted time: 0 <= t_min < t_max or nothing
+    for bad in (dict(t_min=-0.5), dict(t_min=float("nan")), dict(t_min=5.0, t_max=5.0), dict(t_max=float("nan")), dict(t_max=-1.0)):
+        for call in (ctx.render, ctx.render_static):
+            with pytest.raises(capi.PtxError) as e:
+                call(u, cam, capi.default_params(**bad))
+            assert e.value.code == capi.PTX_ERR_INVALID, bad
+    ctx.render(u, cam, capi.default_params(t_min=0.0))                # zero is allowed
     with pytest.raises(capi.PtxError) as e:
         ctx._check(ctx._L.ptx_read_image(ctx.handle, capi.IMAGE_ALBEDO, np.zeros(4, np.float32).ctypes.data, 16))
     assert e.value.code == capi.PTX_ERR_INVALID
@@ -189,6 +237,41 @@ def test_frames_in_flight_equal_serial_frames(oracle, monkeypatch):
     cam1 = oracle.camera_matrices([0.4, 1.1, 3.5], oracle.yaw_quat(8.0), np.deg2rad(np.float32(40)), 160 / 120, 0.1, 1000.0)
     want = sc.render(cam1, 160, 120, 3, SEED, params=oracle.default_params(max_depth=8))
     assert_images_bit_equal(serial[0], want, "serial frames vs oracle")
+
+
+def test_options_are_per_context_and_change_no_bit(oracle, gpu_ctx_factory):
+    """ptx_set_option: two contexts of one process with different scheduling knobs (frames in flight, chunk size, fused
+    tail, traversal grid, shading grid) give the same bits; values read back; bad keys / values are refused."""
+    from path_tracer_amd import capi
+    ing = cornell()
+    cam = oracle.camera_matrices([0, 1.0, 3.9], oracle.yaw_quat(0), np.deg2rad(np.float32(40)), 160 / 120, 0.1, 1000.0)
+    a, b = gpu_ctx_factory(), gpu_ctx_factory()
+    assert a.get_option(capi.OPTION_FRAMES_IN_FLIGHT) == 2 and a.get_option(capi.OPTION_TAIL_RAYS) == 65536
+    assert a.get_option(capi.OPTION_TARGET_PATHS) == 32 << 20 and a.get_option(capi.OPTION_SHADE_GRID) == 8192
+    for key, value in ((capi.OPTION_FRAMES_IN_FLIGHT, 4), (capi.OPTION_TARGET_PATHS, 160 * 120 * 3), (capi.OPTION_TAIL_RAYS, 0),
+                       (capi.OPTION_TAIL_SHIFT, 3), (capi.OPTION_EXTEND_WAVES, 640), (capi.OPTION_SHADE_GRID, 64)):
+        b.set_option(key, value)
+        assert b.get_option(key) == value
+        assert a.get_option(key) != value                             # the other context keeps its own
+    b.set_option(capi.OPTION_EXTEND_WAVES, 0)
+    assert b.get_option(capi.OPTION_EXTEND_WAVES) == a.get_option(capi.OPTION_EXTEND_WAVES)   # 0 = what the device holds
+    b.set_option(capi.OPTION_EXTEND_WAVES, 640)
+    for key, value in ((capi.OPTION_FRAMES_IN_FLIGHT, 0), (capi.OPTION_FRAMES_IN_FLIGHT, 5), (capi.OPTION_TAIL_SHIFT, 32),
+                       (capi.OPTION_TARGET_PATHS, 100), (capi.OPTION_MATERIAL_SORT, 2), (0, 1), (99, 1)):
+        with pytest.raises(capi.PtxError) as e:
+            b.set_option(key, value)
+        assert e.value.code == capi.PTX_ERR_INVALID
+    with pytest.raises(capi.PtxError):
+        b.get_option(99)
+    outs = []
+    for ctx in (a, b):
+        upload(ctx, ing, oracle)
+        gpu_render(ctx, oracle, cam, 160, 120, 2, params=capi.default_params(max_depth=8))      # a learns its queue lengths (fused tail)
+        outs.append(gpu_render(ctx, oracle, cam, 160, 120, 7, params=capi.default_params(max_depth=8)))
+    assert_images_bit_equal(outs[1], outs[0], "context with other options")
+    assert a.stats()["tail_launches"] > 0 and b.stats()["tail_launches"] == 0
+    want = oracle.scene_from_ingest(ing).render(cam, 160, 120, 7, SEED, params=oracle.default_params(max_depth=8))
+    assert_images_bit_equal(outs[1], want, "options vs oracle")
 
 
 def test_c5_converged_4096spp_rel_mse(oracle, gpu_ctx_factory, standins_ready):

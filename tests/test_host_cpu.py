@@ -24,6 +24,20 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(H, name), name
 
 
+def test_option_keys_match_the_header():
+    """ptx_set_option / ptx_get_option: the Python binding's keys are the header's enum, and NULL contexts are refused
+    without touching a GPU."""
+    from path_tracer_amd import capi
+    header = open(os.path.join(ROOT, "include", "ptx.h")).read()
+    enum = dict((k, int(v)) for k, v in re.findall(r"(PTX_OPTION_[A-Z_]+) = (\d+)", header))
+    assert len(enum) == 9
+    for name, value in enum.items():
+        assert getattr(capi, name[4:]) == value, name
+    L = capi.load()
+    assert L.ptx_set_option(None, 1, 2) == capi.PTX_ERR_INVALID
+    assert L.ptx_get_option(None, 1, None) == capi.PTX_ERR_INVALID
+
+
 def test_struct_layouts_match_the_reference_glsl():
     from path_tracer_amd import capi
     assert capi.VERTEX_DTYPE.itemsize == 48 and capi.VERTEX_DTYPE.fields["normal"][1] == 16 and capi.VERTEX_DTYPE.fields["uv"][1] == 32

@@ -97,3 +97,27 @@ def test_render_static_matches_oracle_and_rejects_what_it_cannot_hold(oracle, gp
     assert e.value.code == capi.PTX_ERR_INVALID
     ctx.render_static(u, cam)                           # and still works afterwards
     ctx.synchronize()
+
+
+def test_render_static_two_contexts_back_to_back_without_synchronize(oracle, gpu_ctx_factory):
+    """Two contexts of one GPU share that GPU's scratch array and run on different streams.  Their static frames, issued
+    alternately from this one thread with NO ptx_synchronize in between, are ordered on the device by the per-device
+    event of ptx_render_static; each context's image must equal its own ptx_render frames."""
+    from path_tracer_amd import capi
+    ing = lion_boulder()
+    a, b, ref = gpu_ctx_factory(), gpu_ctx_factory(), gpu_ctx_factory()
+    for c in (a, b, ref):
+        upload(c, ing, oracle)
+    params = capi.default_params(max_depth=16)
+    views = (((320, 240), [2.0, 0.25, 0.6]), ((256, 160), [1.2, 0.6, 2.2]))
+    cams = [copy_struct(capi.Camera, oracle.camera_matrices(pos, oracle.yaw_quat(0), np.deg2rad(np.float32(70)), w / h, 0.1, 1000.0))
+            for (w, h), pos in views]
+    want = [_frames(ref, cam, w, h, 6, params, static=False) for ((w, h), _), cam in zip(views, cams)]
+    for c, ((w, h), _) in zip((a, b), views):
+        c.resize(w, h)
+    for s in range(6):
+        u = capi.Uniforms(1, SEED, s, 0.1, 100.0, (0, 0, 0))
+        a.render_static(u, cams[0], params)
+        b.render_static(u, cams[1], params)
+    assert_images_bit_equal(_images(a), want[0], "context a, interleaved static frames")
+    assert_images_bit_equal(_images(b), want[1], "context b, interleaved static frames")
