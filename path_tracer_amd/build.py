@@ -87,7 +87,35 @@ def build_library(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, extra_flags):
+    """A developer build of both libraries with extra compiler flags into probe_libs/<name>/ (git-ignored; travels to the
+    GPU box), loaded with PTX_LIB_DIR=probe_libs/<name>.  The product libraries are left alone."""
+    root = os.path.dirname(HERE)
+    out = os.path.join(root, "probe_libs", name)
+    bdir = os.path.join(HERE, "_build", "variant_" + name)
+    os.makedirs(out, exist_ok=True)
+    os.makedirs(bdir, exist_ok=True)
+    procs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(bdir, src + ".o")
+        cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    lib = os.path.join(out, "libptx_amd.so")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl", "-lpthread"])
+    cmd = [CXX, "-O2", "-std=c++17", "-Wall", "-Wextra", "-ffp-contract=off", "-fPIC", "-shared", "-o", os.path.join(out, "libpt_host.so")]
+    cmd += [os.path.join(HOST_DIR, f) for f in HOST_SOURCES] + ["-L" + out, "-lptx_amd", "-Wl,-rpath,$ORIGIN", "-lz"]
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
+    if len(sys.argv) >= 3 and sys.argv[1] == "--variant":
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+        sys.exit(0)
     build_library(force="--force" in sys.argv, verbose=True)
     build_host(force="--force" in sys.argv, verbose=True)
     build_cli(force="--force" in sys.argv, verbose=True)

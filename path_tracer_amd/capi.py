@@ -99,7 +99,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = os.environ.get("PTX_LIB", LIB_PATH)      # developer override: an alternative build of the same library
+    # developer overrides: an alternative build of the same library (PTX_LIB), or a directory holding alternative
+    # builds of this library and of libpt_host.so (PTX_LIB_DIR, tools/ab.sh) -- the product files are never overwritten
+    path = os.environ.get("PTX_LIB") or (os.path.join(os.environ["PTX_LIB_DIR"], "libptx_amd.so") if os.environ.get("PTX_LIB_DIR") else LIB_PATH)
     if not os.path.exists(path):
         raise RuntimeError("%s is missing: run `python -m path_tracer_amd.build` (hipcc, gfx950)" % path)
     L = C.CDLL(path)

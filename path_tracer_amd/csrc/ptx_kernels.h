@@ -132,7 +132,7 @@ constexpr uint64_t kMaxSceneTriangles = (1ull << kTriIndexBits) - 1ull;
 
 // traversal stack: entries held in LDS per lane, remainder in private memory
 #ifndef PTX_LDS_STACK
-#define PTX_LDS_STACK 6      // 6 x 8 B x 64 lanes = 3 KB of the traversal kernel's 5 KB-per-wave LDS budget (8 waves per SIMD)
+#define PTX_LDS_STACK 5      // 5 x 8 B x 64 lanes = 2.5 KB of the traversal kernel's 5 KB-per-wave LDS budget (8 waves per SIMD; 5 measured = 6 = 7)
 #endif
 constexpr int kLdsStack = PTX_LDS_STACK;
 constexpr int kOvfStack = 32 - PTX_LDS_STACK;

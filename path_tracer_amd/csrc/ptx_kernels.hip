@@ -80,13 +80,14 @@ __global__ void __launch_bounds__(256) k_raygen(FrameDev f, uint32_t n_paths, Ra
 //  * Wave-level triangle queue: a lane that hits leaves does not test their triangles itself (the
 //    triangle code would run for the ~20 of 64 lanes that happen to have one pending, r01e).  The
 //    triangles go to a per-wave FIFO in LDS as (triangle, owner lane) pairs and the owner carries
-//    on down the tree; when enough pairs have collected (48), ANY lane tests ANY pair (ray fetched from
-//    the owner with ds_bpermute) and successful tests are handed back to their owners.  Closest
+//    on down the tree; when enough pairs have collected (36), ANY lane tests ANY pair (the owner's ray --
+//    origin, direction, current closest t -- read from the wave's LDS block) and successful tests are
+//    handed back to their owners with an LDS atomic minimum.  Closest
 //    hit with the (instance, primitive) tie-break is order-independent, so the image is unchanged;
 //    a ray is complete once its node walk is done and the FIFO head has passed its last pair.
 //  * Nodes are loaded straight into registers; what pays is occupancy without register spills -- 8 waves/SIMD
-//    at 64 VGPRs and 4.9 KB of LDS per wave (the 25 overflow entries of the traversal stack are a private
-//    array: 208 B of scratch per lane, touched only by rays that nest deeper than 7 groups).  At that
+//    at 64 VGPRs and 5.0 KB of LDS per wave (the 27 overflow entries of the traversal stack are a private
+//    array: 224 B of scratch per lane, touched only by rays that nest deeper than 5 groups).  At that
 //    occupancy the kernel uses 62 % of the SIMDs' vector issue capacity (profiles/valu.json, priced with
 //    the per-class issue costs of profiles/r02_valu_calibration.json); 30 % of a wave's life is waiting
 //    for memory, 43 % waiting for an issue slot.
@@ -116,6 +117,9 @@ struct LaneStack {
     __device__ __forceinline__ bool empty() const { return sp == 0; }
 };
 
+// __ballot() takes an int: the bool is widened and compared again (v_cndmask + v_cmp per call in the traversal loop)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // After a node test: make the next node group current and take its nearest pending child -- Traversal::next_group +
 // node_pick written without divergent regions (the probe sweep of tools/probe_sweep.sh prices a scalar instruction
 // of this kernel at 0.13 % of its run time, a vector one at 0.19 - 0.26 %; the branchy form spent ~25 scalar
@@ -125,7 +129,7 @@ struct LaneStack {
 template <class Trav>
 __device__ __forceinline__ uint32_t advance_walk(Trav &tr, LaneStack &st)
 {
-    if (__builtin_expect(__ballot(st.sp >= kLdsStack) != 0ull, 0)) return tr.next_group(st) ? tr.node_pick(st) : 0xFFFFFFFFu;
+    if (__builtin_expect(ballot64(st.sp >= kLdsStack) != 0ull, 0)) return tr.next_group(st) ? tr.node_pick(st) : 0xFFFFFFFFu;
     const bool has = (tr.ng_mask & 0xFF000000u) != 0u;
     const int top_i = st.sp > 0 ? st.sp - 1 : 0;
     const uint32_t top_base = st.lds[top_i * kExtendBlock].x, top_mask = st.lds[top_i * kExtendBlock].y;
@@ -185,17 +189,27 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
     return (uint32_t)x;
 }
 
-__device__ __forceinline__ float lane_read_f(float v, uint32_t src_lane)
-{
-    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
-}
-__device__ __forceinline__ uint32_t lane_read_u(uint32_t v, uint32_t src_lane)
-{
-    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
-}
-
 //  * kAnyHit (occlusion rays of the lit integrator): the first accepted triangle ends the ray's walk;
 //    hits[ray].tri != miss then only means "occluded".
+// pt_math.h tri_test_t with the same expression trees and the same accept / reject decisions, evaluated without early
+// exits: in a block of ~59 pairs some lane passes the edge test practically always, so the division ran anyway, and each
+// early exit cost a handful of scalar EXEC instructions per block.  `ht`: the owner's current closest t.
+__device__ __forceinline__ bool tri_test_flat(f3 o, f3 d, f3 v0, f3 v1, f3 v2, float t_min, float t_max, float ht, float &t_out)
+{
+    const f3 A = v0 - o, B = v1 - o, C = v2 - o;
+    const float U = dot(d, cross(C - B, C + B));
+    const float V = dot(d, cross(A - C, A + C));
+    const float W = dot(d, cross(B - A, B + A));
+    const bool mixed = (U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f);
+    const float det = (U + V) + W;
+    const f3 Ng = cross(B - A, C - A);
+    const float den = dot(d, Ng);
+    const float t = dot(A, Ng) / den;
+    t_out = t;
+    return !mixed & (det != 0.0f) & (t > t_min) & (t < t_max) & (t <= ht);
+}
+
+constexpr uint32_t kWalked = 0xFFFFFFFFu, kIdle = 0xFFFFFFFEu, kNoRay = 0xFFFFFFFFu;
 template <bool kStats, bool kAnyHit>
 __global__ void __launch_bounds__(kExtendBlock) __attribute__((amdgpu_waves_per_eu(PTX_EXTEND_WAVES_PER_EU, PTX_EXTEND_WAVES_PER_EU)))
 k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *__restrict__ count,
@@ -206,6 +220,7 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
     __shared__ uint32_t s_qtri[kTriQueue];      // pending (triangle, owner lane) pairs: triangle index | owner << kTriIndexBits
     __shared__ unsigned long long s_best[kExtendBlock];   // closest hit of each lane's ray as one ordered word: float bits of t << 32 | TriRec::rank
     __shared__ float s_dir[3][kExtendBlock];      // direction of each lane's ray: the triangle block reads its pair owner's
+    __shared__ float s_org[3][kExtendBlock];      // ... and its origin
     const uint32_t n = *count;
     const uint32_t lane_id = threadIdx.x;
     uint2 ovf_store[kOvfStack];
@@ -217,10 +232,13 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
     tr.ng_mask = 0; tr.tg_mask = 0;
     tr.o = mk3(0.0f, 0.0f, 0.0f); tr.hit.t = 0.0f;
     tr.t_min = t_min; tr.t_max = t_max;     // wave-uniform: keeps them out of the VGPRs
-    bool active = false;
-    bool unwritten = false;             // this lane's finished ray has not been stored yet: all such lanes store together at the next refill
-    uint32_t ray = 0;
-    uint32_t next_ni = 0xFFFFFFFFu;
+    // Lane state without separate flags (r03): a boolean carried round the loop lives in an SGPR pair, and every merge
+    // of it across a divergent region costs the compiler three scalar mask operations, every ballot of it a v_cndmask +
+    // v_cmp.  next_ni says it all: a node index (the walk goes on), kWalked (the walk is over, the ray waits for its last
+    // queued triangles) or kIdle (no live ray).  ray != kNoRay on an idle lane: its finished ray has not been stored yet --
+    // all such lanes store together at the next refill.
+    uint32_t ray = kNoRay;
+    uint32_t next_ni = kIdle;
     uint32_t q_head = 0, q_tail = 0;    // wave-uniform, monotone (mod 2^32)
     uint32_t my_tail = 0;               // q_tail just after this lane's latest pair
     unsigned long long tot_nodes = 0, tot_tris = 0;
@@ -260,16 +278,20 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
     bool exhausted = (uint64_t)(blockIdx.x / kFetchHeads) * chunk >= seg || n == 0;
 
     for (;;) {
-        unsigned long long idle = __ballot(!active);
+        unsigned long long idle = ballot64(next_ni == kIdle);
         if (!exhausted && __popcll(idle) >= sched.refill) {
             if (kStats) w_refills++;
             // The results of the rays that finished since the last refill leave in ONE store here.  A store per
             // iteration (a few lanes retire in almost every one) sat in front of every node fetch: vmcnt counts
-            // loads and stores together and in order, so each fetch also waited for the store before it.
-            if (unwritten) {
-                *reinterpret_cast<float2 *>(hits + ray) = make_float2(tr.hit.t, __uint_as_float(tr.hit.tri));
-                unwritten = false;
-            }
+            // loads and stores together and in order, so each fetch also waited for the store before it.  The closest
+            // hit was kept by rank; the stages downstream index triangles in leaf order (an occlusion query only
+            // reports hit / miss): that gather goes out first and comes back behind the new rays' loads for free.
+            const bool pending = next_ni == kIdle && ray != kNoRay;
+            const uint32_t old_ray = ray;
+            const float old_t = tr.hit.t;
+            uint32_t old_tri = tr.hit.tri;
+            if (!kAnyHit && pending && old_tri != 0xFFFFFFFFu) old_tri = sc.tri_of_rank[old_tri];
+            if (pending) ray = kNoRay;
             for (int pass = 0; pass < 2 && idle != 0ull; ++pass) {
                 if (chunk_next == chunk_end) {
                     bool got = false;
@@ -294,7 +316,7 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                 }
                 uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 uint32_t avail = chunk_end - chunk_next;
-                if (!active && rank < avail) {
+                if (next_ni == kIdle && rank < avail) {
                     uint32_t i = chunk_next + rank;
                     const float4 r1 = rays.dir[i];
                     const float4 r0 = sched.primary ? make_float4(sched.cam_o[0], sched.cam_o[1], sched.cam_o[2], __uint_as_float(i)) : rays.org[i];
@@ -303,54 +325,57 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                     float ix, iy, iz;
                     const uint32_t oct = ray_slab_setup_rcp(mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), ix, iy, iz);
                     bool go = tr.init_prepared(sc.n_nodes, mk3(r0.x, r0.y, r0.z), ix, iy, iz, oct, t_min, t_max, st);
-                    next_ni = go ? tr.node_pick(st) : 0xFFFFFFFFu;
+                    next_ni = go ? tr.node_pick(st) : kWalked;
                     ray = i;
                     my_tail = q_head;
-                    active = true;
                     s_dir[0][lane_id] = r1.x; s_dir[1][lane_id] = r1.y; s_dir[2][lane_id] = r1.z;
+                    s_org[0][lane_id] = r0.x; s_org[1][lane_id] = r0.y; s_org[2][lane_id] = r0.z;
                     s_best[lane_id] = ((unsigned long long)__float_as_uint(t_max) << 32) | 0xFFFFFFFFull;
                 }
                 uint32_t n_idle = (uint32_t)__popcll(idle);
                 chunk_next += (n_idle < avail) ? n_idle : avail;
-                idle = __ballot(!active);
+                idle = ballot64(next_ni == kIdle);
             }
+            if (pending) *reinterpret_cast<float2 *>(hits + old_ray) = make_float2(old_t, __uint_as_float(old_tri));
         }
         PTX_PHASE(0);
-        if (__ballot(active) == 0) {
+        if (ballot64(next_ni != kIdle) == 0) {
             if (exhausted) break;
             continue;
         }
         const int stop_at = exhausted ? 0 : (64 - sched.refill);
         do {
             // ---- node visits: every lane whose walk is not finished and whose last leaf hits are queued
-            bool want_node = active && tr.tg_mask == 0 && next_ni != 0xFFFFFFFFu;
-            const int nb = __popcll(__ballot(want_node));
-            if (kStats) { w_iters++; if (nb) { w_node_blocks++; w_node_lanes += nb; } }
-            if (nb > 0) {
-                if (kStats) {
-                    Words80 nw;
-                    if (want_node) nw = load_node(sc.nodes, next_ni);
-                    PTX_PHASE(1);
-                    if (want_node) {
-                        tr.node_eval(nw);
-                        next_ni = advance_walk(tr, st);
-                    }
-                    PTX_PHASE(2);
-                } else if (want_node) {
-                    tr.node_eval(load_node(sc.nodes, next_ni));
+            // (a ballot per comparison, combined as scalars: the ballot of a conjunction is widened to a VGPR and compared
+            // again, v_cndmask + v_cmp, because the compiler cannot see that the AND of two v_cmp results lies inside EXEC)
+            const bool no_tris = tr.tg_mask == 0, walking = next_ni < kIdle;
+            const bool want_node = no_tris && walking;
+            if (kStats) {
+                const int nb = __popcll(ballot64(no_tris) & ballot64(walking));
+                w_iters++;
+                if (nb) { w_node_blocks++; w_node_lanes += nb; }
+                Words80 nw;
+                if (want_node) nw = load_node(sc.nodes, next_ni);
+                PTX_PHASE(1);
+                if (want_node) {
+                    tr.node_eval(nw);
                     next_ni = advance_walk(tr, st);
                 }
+                PTX_PHASE(2);
+            } else if (want_node) {      // (no wave-uniform guard: an empty EXEC skips the block by itself)
+                tr.node_eval(load_node(sc.nodes, next_ni));
+                next_ni = advance_walk(tr, st);
             }
             // ---- queue the triangles of the leaves just hit: wave prefix sum of the per-lane counts
             //      (six DPP adds), then every lane writes its own run of the FIFO
-            if (__ballot(tr.tg_mask != 0) != 0ull) {
+            if (ballot64(tr.tg_mask != 0) != 0ull) {
                 const uint32_t room = kTriQueue - (q_tail - q_head);
                 const uint32_t cnt = (uint32_t)__popc(tr.tg_mask);
                 const uint32_t incl = wave_inclusive_sum(cnt);
                 // lanes whose whole group fits form a prefix (incl is monotone); the others keep
                 // their group and stay out of the node block until the FIFO has drained
                 const bool fits = incl <= room;
-                const uint32_t n_fit = (uint32_t)__popcll(__ballot(fits));
+                const uint32_t n_fit = (uint32_t)__popcll(ballot64(fits));
                 const uint32_t total = n_fit ? (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)n_fit - 1) : 0u;
                 if (fits && cnt) {
                     uint32_t pos = q_tail + incl - cnt;
@@ -368,69 +393,77 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
             // ---- triangle tests, a full wave's worth at a time
             {
                 const uint32_t qn = q_tail - q_head;
-                const bool walked = active && next_ni == 0xFFFFFFFFu && tr.tg_mask == 0;
-                const int n_wait = __popcll(__ballot(walked && (int)(q_head - my_tail) < 0));
-                const int n_node = __popcll(__ballot(active && tr.tg_mask == 0 && next_ni != 0xFFFFFFFFu));
+                const unsigned long long m_no_tris = ballot64(tr.tg_mask == 0);
+                const int n_wait = __popcll(ballot64(next_ni == kWalked) & m_no_tris & ballot64((int)(q_head - my_tail) < 0));
+                const int n_node = __popcll(ballot64(next_ni < kIdle) & m_no_tris);
                 if (qn >= (uint32_t)sched.tri_min || (qn > 0u && (n_wait >= sched.flush_min || n_node == 0))) {
                     wave_lds_sync();
                     const uint32_t nt = qn < 64u ? qn : 64u;
                     if (kStats) { w_tri_blocks++; w_tri_lanes += nt; }
                     const bool has = lane_id < nt;
-                    const uint32_t idx = (q_head + lane_id) & (kTriQueue - 1u);
-                    const uint32_t entry = has ? s_qtri[idx] : (lane_id << kTriIndexBits);
-                    const uint32_t ti = entry & ((1u << kTriIndexBits) - 1u), own = entry >> kTriIndexBits;
-                    // the owner's ray: origin and current closest t from its registers (ds_bpermute), direction from
-                    // the wave's LDS block (not kept in registers: the node walk only needs 1 / d; re-reading it from
-                    // the ray queue put a cold global load on the block's dependent chain)
-                    f3 o = mk3(lane_read_f(tr.o.x, own), lane_read_f(tr.o.y, own), lane_read_f(tr.o.z, own));
-                    float ht = lane_read_f(tr.hit.t, own);
-                    float t = 0.0f;
+                    // One pair per lane.  Everything about the owner's ray comes out of the wave's LDS block -- origin,
+                    // direction, and the current closest t from s_best[own], the master copy of (t, rank) that tr.hit only
+                    // mirrors -- so the whole test sits under ONE predicate (r02 fetched origin and t with four ds_bpermute,
+                    // which every lane has to execute, and so split the block in two with 14 registers zeroed in between).
+                    uint32_t own = lane_id;
+                    float t = 0.0f, rank_bits = 0.0f;
                     bool cand = false;
-                    f3 dd = mk3(0.0f, 0.0f, 1.0f);
-                    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
-                    if (has) {
-                        dd = mk3(s_dir[0][own], s_dir[1][own], s_dir[2][own]);
+                    f3 o, dd; float ht; float4 r0, r1, r2;
+                    auto fetch = [&]() {
+                        const uint32_t entry = s_qtri[(q_head + lane_id) & (kTriQueue - 1u)];
+                        const uint32_t ti = entry & ((1u << kTriIndexBits) - 1u);
+                        own = entry >> kTriIndexBits;
                         const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + ti);
                         r0 = tp[0]; r1 = tp[1]; r2 = tp[2];
-                    }
-                    PTX_PHASE(4);
-                    if (has) {
-                        cand = tri_test_t(o, dd, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), mk3(r2.x, r2.y, r2.z),
-                                          t_min, t_max, t) && t <= ht;
+                        o = mk3(s_org[0][own], s_org[1][own], s_org[2][own]);
+                        dd = mk3(s_dir[0][own], s_dir[1][own], s_dir[2][own]);
+                        ht = __uint_as_float(reinterpret_cast<const uint32_t *>(s_best)[own * 2u + 1u]);
+                    };
+                    auto test = [&]() {
+                        cand = tri_test_flat(o, dd, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), mk3(r2.x, r2.y, r2.z), t_min, t_max, ht, t);
+                        rank_bits = r2.w;
                         if (kStats) tot_tris++;
+                    };
+                    if (kStats) {
+                        if (has) fetch();
+                        PTX_PHASE(4);
+                        if (has) test();
+                        PTX_PHASE(5);
+                    } else if (has) {
+                        fetch();
+                        test();
                     }
-                    PTX_PHASE(5);
                     q_head += nt;
                     // Hand the successful tests to their owners: one LDS atomic minimum on the owner's (t, rank) word.  t is
                     // positive, so its float bits order like the value; equal distances (shared edges, coincident surfaces)
                     // fall through to the rank = lowest (instance, primitive) wins, the oracle's rule; several pairs of one
                     // owner, in any order, leave the same minimum.  Then every lane reloads its own word.
-                    if (cand) atomicMin(&s_best[own], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)__float_as_uint(r2.w));
+                    if (cand) atomicMin(&s_best[own], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)__float_as_uint(rank_bits));
                     wave_lds_sync();
                     {
+                        // (every lane: the word of an idle lane has not changed since its ray retired)
                         const unsigned long long best = s_best[lane_id];
                         const uint32_t best_rank = (uint32_t)best;
-                        if (active) {
-                            tr.hit.t = __uint_as_float((uint32_t)(best >> 32)); tr.hit.tri = best_rank;
-                            if (kAnyHit && best_rank != 0xFFFFFFFFu) { next_ni = 0xFFFFFFFFu; st.sp = 0; tr.ng_mask = 0; }
-                        }
+                        tr.hit.t = __uint_as_float((uint32_t)(best >> 32)); tr.hit.tri = best_rank;
+                        if (kAnyHit && next_ni != kIdle && best_rank != 0xFFFFFFFFu) { next_ni = kWalked; st.sp = 0; tr.ng_mask = 0; }
                     }
                     PTX_PHASE(6);
                 }
             }
             // ---- rays whose walk is over and whose pairs have all been tested
-            if (active && next_ni == 0xFFFFFFFFu && tr.tg_mask == 0 && (int)(q_head - my_tail) >= 0) {
-                if (kStats) tot_nodes += tr.stats.nodes;
-                active = false;
-                unwritten = true;
-                // the closest hit was kept by rank; the stages downstream index triangles in leaf order (an occlusion
-                // query only reports hit / miss)
-                if (!kAnyHit && tr.hit.tri != 0xFFFFFFFFu) tr.hit.tri = sc.tri_of_rank[tr.hit.tri];
+            {
+                const bool retire = next_ni == kWalked && tr.tg_mask == 0 && (int)(q_head - my_tail) >= 0;
+                if (kStats && retire) tot_nodes += tr.stats.nodes;
+                next_ni = retire ? kIdle : next_ni;      // (t, rank) stay in the registers until the next refill stores them
             }
             PTX_PHASE(7);
-        } while (__popcll(__ballot(active)) > stop_at);
+        } while (__popcll(ballot64(next_ni != kIdle)) > stop_at);
     }
-    if (unwritten) *reinterpret_cast<float2 *>(hits + ray) = make_float2(tr.hit.t, __uint_as_float(tr.hit.tri));
+    if (next_ni == kIdle && ray != kNoRay) {
+        uint32_t tri = tr.hit.tri;
+        if (!kAnyHit && tri != 0xFFFFFFFFu) tri = sc.tri_of_rank[tri];
+        *reinterpret_cast<float2 *>(hits + ray) = make_float2(tr.hit.t, __uint_as_float(tri));
+    }
     if (kStats) {
         atomicAdd(&trav_totals[0], tot_nodes);
         atomicAdd(&trav_totals[1], tot_tris);
@@ -1411,7 +1444,7 @@ static const ExtendSched &extend_sched()
 {
     static const ExtendSched sched = [] {
         auto knob = [](const char *name, int dflt) { const char *e = getenv(name); int v = e ? atoi(e) : dflt; return v < 1 ? 1 : (v > 64 ? 64 : v); };
-        ExtendSched k{}; k.refill = knob("PTX_REFILL", 12); k.tri_min = knob("PTX_TRI_MIN", 48); k.flush_min = knob("PTX_FLUSH_MIN", 8);
+        ExtendSched k{}; k.refill = knob("PTX_REFILL", 14); k.tri_min = knob("PTX_TRI_MIN", 36); k.flush_min = knob("PTX_FLUSH_MIN", 8);
         const char *ce = getenv("PTX_CHUNK"); int cv = ce ? atoi(ce) : 128; k.chunk = (uint32_t)(cv < 64 ? 64 : cv);
         k.chunk_grow = (uint32_t)knob("PTX_CHUNK_GROW", 4);
         return k;

@@ -25,9 +25,11 @@ def load():
     if _lib is not None:
         return _lib
     capi.load()
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError("%s is missing: run `python -m path_tracer_amd.build`" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+    # developer override (tools/ab.sh): a directory holding an alternative build of BOTH libraries
+    path = os.path.join(os.environ["PTX_LIB_DIR"], "libpt_host.so") if os.environ.get("PTX_LIB_DIR") else LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: run `python -m path_tracer_amd.build`" % path)
+    L = C.CDLL(path)
     vp = C.c_void_p
     fp = C.POINTER(C.c_float)
     L.pth_last_error.restype = C.c_char_p
