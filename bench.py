@@ -37,6 +37,15 @@ WORKLOADS = {
                          res=(1280, 720), geometry="procedural stand-in (spheres.bin is missing from the reference checkout)"),
     "lion_boulder_1080p": dict(items=[("lion_head_2k/lion_head_2k.gltf", (2, 0, 0)), ("boulder_01_2k/boulder_01_2k.gltf", (-2, 0, 0))],
                                pos=[2.0, 0.25, 0.6], yaw=0.0, fov=70.0, res=(1920, 1080), geometry="real"),
+    # deep incoherent paths through real, non-axis-aligned triangles: the two scanned meshes of the reference's app
+    # (render_window.rs:412-426) inside a closed room (tools/make_room.py), camera inside: no path ends in the sky
+    "lion_boulder_room_1080p": dict(items=[("room/room.gltf", (0, 0, 0)), ("lion_head_2k/lion_head_2k.gltf", (2, 0, 0)),
+                                           ("boulder_01_2k/boulder_01_2k.gltf", (-2, 0, 0))],
+                                    pos=[0.3, 0.55, 1.45], yaw=0.0, fov=70.0, res=(1920, 1080), geometry="real (scanned meshes) in a generated closed room"),
+    # the Sponza stand-in rotated 30 degrees about +Y with the camera rotated along: the same image content, every
+    # triangle oblique to the world axes (looser boxes)
+    "sponza_rot30_1080p": dict(items=[("sponza/Sponza_rot30.gltf", (0, 0, 0))], pos=[-6.928203, 1.6, 4.0], yaw=-60.0, fov=70.0,
+                               res=(1920, 1080), geometry="procedural stand-in, rotated 30 degrees about +Y"),
     "cornell_512": dict(items=[("cornell/cornell.gltf", (0, 0, 0))], pos=[0.0, 1.0, 3.9], yaw=0.0, fov=40.0,
                         res=(512, 512), geometry="real"),
 }
@@ -68,7 +77,15 @@ def main():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the N > 1 path on a box with ONE GPU: every rank renders on device 0 and the "
                          "accumulation reduce goes through host memory over gloo (RCCL refuses two ranks on one device)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    ap.add_argument("--total-spp", type=int, default=0,
+                    help="fixed-budget mode (BASELINE.json configs 3 and 5: '1024 spp partitioned over 8 GPUs'): the JOB renders "
+                         "this many samples per pixel in all, split over the ranks by partition_samples, and the timed region is the "
+                         "time to the combined image, reduce included -> \"scaling\": \"strong\".  --steps is then derived "
+                         "(ceil(rank's share / --spp-per-step) batches, the last one short); 0 (default): weak scaling, --steps "
+                         "batches of --spp-per-step on every rank")
+    ap.add_argument("--traffic-json", default=None,
+                    help="PMC-derived HBM traffic of the traversal kernel (default: profiles/traffic.json, or traffic_lit.json for "
+                         "--integrator lit); valu*.json is read from the same directory")
     ap.add_argument("--launch-check", action="store_true",
                     help="only bring up the N ranks, check the world size with one all-reduce and print a JSON line; no "
                          "GPU is touched when combined with --rehearse-gloo (the CPU test of the launcher path)")
@@ -142,8 +159,18 @@ def main():
     r.set_seed(SEED, fixed=True)
     from path_tracer_amd.multi_gpu import combine_accumulation, partition_samples
     spp = args.spp_per_step
-    # the job's budget is world x (steps + warmup) x spp samples per pixel; rank g renders slice g of it
-    first_sample, _ = partition_samples(world * (args.steps + args.warmup) * spp, world, rank)
+    strong = args.total_spp > 0
+    if strong:
+        # fixed budget: the job renders --total-spp samples per pixel, rank g the slice partition_samples gives it (the
+        # warm-up batches use sample indices past the budget and are overwritten: the accumulation restarts below)
+        first_sample, my_spp = partition_samples(args.total_spp, world, rank)
+        batches = [spp] * (my_spp // spp) + ([my_spp % spp] if my_spp % spp else [])
+        job_budget = args.total_spp
+    else:
+        # the job's budget is world x (steps + warmup) x spp samples per pixel; rank g renders slice g of it
+        job_budget = world * (args.steps + args.warmup) * spp
+        first_sample, _ = partition_samples(job_budget, world, rank)
+        batches = [spp] * args.steps
     params = capi.default_params(max_depth=args.max_depth, rng_sample_offset=first_sample,
                                  integrator=capi.INTEGRATOR_LIT if lit else capi.INTEGRATOR_REFERENCE)
     r.set_params(params)
@@ -152,6 +179,12 @@ def main():
         r.record_commands_batch(spp)
     ctx.synchronize()
     load_s = time.time() - t0
+    if strong:
+        # time-to-image starts from an empty accumulation: the image of the timed region is the job's image
+        r.resize_render_buffer(W, H)  # resized_dirty: the next frame restarts the accumulation (renderer.rs:583-666, 988-1000)
+        r.record_commands()           # ... that dirty frame: 1 spp, overwritten by the first clean one
+        ctx.synchronize()
+        assert r.accumulated_count == 0, r.accumulated_count
 
     red = None
     if dist is not None:
@@ -170,10 +203,12 @@ def main():
     torch.cuda.synchronize()
     ctx.synchronize()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        r.record_commands_batch(spp)
+    for b in batches:
+        r.record_commands_batch(b)
+    t_render = None
     if dist is not None:
-        ctx.export_albedo_device(red.data_ptr(), red.numel() * 4, 1.0)
+        ctx.export_albedo_device(red.data_ptr(), red.numel() * 4, 1.0)      # (synchronises the context: every batch has finished)
+        t_render = time.perf_counter() - t_start
         if args.rehearse_gloo:
             host_img = red.cpu()
             combined = combine_accumulation(host_img, dist, world, root=0)
@@ -190,8 +225,17 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
+    if t_render is None:
+        t_render = elapsed
     st = ctx.stats()
     ctx.set_profiling(0)
+    # the line decomposed per rank: scene load + warm-up, rendering alone, the accumulation reduce (export, collective, import)
+    mine = [load_s, t_render * 1e3, (elapsed - t_render) * 1e3, float(sum(batches))]
+    per_rank = [mine]
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
 
     if dist is not None:
         stat_dev = "cpu" if args.rehearse_gloo else "cuda:%d" % local_rank
@@ -215,7 +259,7 @@ def main():
         acc = np.zeros((H, W, 4), np.float64)
         for g in range(world):
             ctx.resize(W, H)
-            first_g, _ = partition_samples(world * (args.steps + args.warmup) * spp, world, g)
+            first_g, _ = partition_samples(job_budget, world, g)
             ctx.render_batch(capi.Uniforms(1, SEED, 0, 0.1, 100.0, (0, 0, 0)), gcam, n_acc,
                              capi.default_params(max_depth=args.max_depth, rng_sample_offset=first_g,
                                                  integrator=capi.INTEGRATOR_LIT if lit else capi.INTEGRATOR_REFERENCE))
@@ -257,27 +301,50 @@ def main():
         achieved_tflops = lane_ops_per_ray * 2.0 * rays_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
         bytes_per_ray = nodes_per_ray * NODE_BYTES + tris_per_ray * TRI_BYTES + RAY_BYTES + HIT_BYTES
         req_gbs = bytes_per_ray * rays_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        # Counter-derived side fields come from the committed rocprofv3 --pmc summaries (profiles/traffic*.json,
+        # valu*.json; PMC passes cannot run inside a timed bench).  They are only quoted when they were measured on THESE
+        # sources and THIS workload: the summaries carry a hash of path_tracer_amd/csrc + include/ptx.h
+        # (tools/profile_round_summary.py); after any kernel change the line says "profile_stale": true and the
+        # fields are null until tools/profile_round.sh has been re-run.
+        from path_tracer_amd import build as pbuild
+        src_hash = pbuild.csrc_hash()
+        wl_key = args.workload + ("+lit" if lit else "")
+        suffix = "_lit" if lit else ""
+        traffic_json = args.traffic_json or os.path.join(ROOT, "profiles", "traffic%s.json" % suffix)
         traffic = None
         tcc_hit = None
-        if os.path.exists(args.traffic_json):
+        shade_hbm_per_ray = None
+        profile_stale = None        # None: no summary for this workload; True: one exists, measured on other sources
+        if os.path.exists(traffic_json):
             try:
-                tj = json.load(open(args.traffic_json))
-                if tj.get("workload") == args.workload:
-                    # PMC passes run on a shorter job; scale the measured HBM-side bytes per ray to this run's launch size
-                    traffic = round(tj["hbm_bytes_per_ray"] * rays_per_launch, 1)
-                    tcc_hit = tj.get("tcc_hit_rate")
+                tj = json.load(open(traffic_json))
+                if tj.get("workload") == wl_key:
+                    profile_stale = tj.get("csrc_sha16") != src_hash
+                    if not profile_stale:
+                        # PMC passes run on a shorter job; scale the measured HBM-side bytes per ray to this run's launch size
+                        traffic = round(tj["hbm_bytes_per_ray"] * rays_per_launch, 1)
+                        tcc_hit = tj.get("tcc_hit_rate")
+                        shade_hbm_per_ray = tj.get("shade_hbm_bytes_per_ray")
             except Exception:
                 traffic = None
         valu = None
-        vj = os.path.join(os.path.dirname(args.traffic_json), "valu.json")
+        valu_shade = None
+        vj = os.path.join(os.path.dirname(traffic_json), "valu%s.json" % suffix)
         if os.path.exists(vj):
             try:
                 d = json.load(open(vj))
-                if d.get("workload") == args.workload:
-                    k = d["kernels"].get("k_extend<false, false>") or d["kernels"]["k_extend<false>"]
-                    valu = {x: (round(y, 4) if isinstance(y, float) else y) for x, y in k.items() if x != "counters"}
-                    valu["source"] = d.get("source", "profiles/valu.json")
-                    valu["definitions"] = d.get("definitions")
+                if d.get("workload") == wl_key:
+                    stale_v = d.get("csrc_sha16") != src_hash
+                    profile_stale = bool(profile_stale) or stale_v
+                    if not stale_v:
+                        def pick(k):
+                            v = {x: (round(y, 4) if isinstance(y, float) else y) for x, y in k.items() if x != "counters"}
+                            v["source"] = d.get("source", "profiles/valu.json")
+                            return v
+                        valu = pick(d["kernels"]["k_extend<false, false>"])
+                        valu["definitions"] = d.get("definitions")
+                        sk = d["kernels"].get("k_shade_lit" if lit else "k_shade")
+                        valu_shade = pick(sk) if sk else None
             except Exception:
                 valu = None
         # HBM view: the traversal-free floor of SURVEY.md 8d (reference data layouts: 212 B (+4 B texel) per hit ray, 32 B of
@@ -319,7 +386,19 @@ def main():
                      ms_per_step=round(ist["shade_ms"], 3),
                      note="HIP-event time of the shading launches of ONE untimed step with every chunk on one stream (nothing overlaps them)")
         shade["frac"] = round(shade["achieved"] / HBM_PEAK_GBS, 5)
+        # `achieved` prices ALGORITHMIC bytes: part of the 128-byte record gathers (a 33.6 MB table) is served by L2 /
+        # Infinity Cache, so it can exceed what HBM itself delivers.  The HBM-side bytes by counter (FETCH_SIZE + WRITE_SIZE
+        # of the same kernel, profiles/traffic*.json) over the same time stand beside it.
+        if shade_hbm_per_ray and ist["shade_ms"] > 0:
+            shade["hbm_counter_bytes_per_ray"] = round(shade_hbm_per_ray, 1)
+            shade["hbm_counter_achieved"] = round(shade_hbm_per_ray * irays / (ist["shade_ms"] * 1e-3) / 1e9, 2)
+            shade["hbm_counter_frac"] = round(shade["hbm_counter_achieved"] / HBM_PEAK_GBS, 5)
+        else:
+            shade["hbm_counter_bytes_per_ray"] = shade["hbm_counter_achieved"] = shade["hbm_counter_frac"] = None
+        shade["valu_issue"] = valu_shade
         roofline["second_kernel"] = shade
+        roofline["profile_stale"] = profile_stale
+        roofline["profile_csrc_sha16"] = src_hash
 
         cpu = None
         parity = None
@@ -329,15 +408,16 @@ def main():
         if cpu_spp > 0:
             cpu, parity = cpu_baseline(r, wl, assets, W, H, cpu_spp, args.max_depth, args.workload, lit)
 
+        ranks_render = [x[1] for x in per_rank]
         out = {
             "metric": "samples/sec (Mrays/s) Sponza 1080p at 1/2/4/8 MI355X; rel-MSE vs ref",
             "value": round(job_samples / elapsed, 1),
             "unit": "samples/s",
             "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
             "collective_backend": (None if dist is None else ("gloo (rehearsal, host-staged)" if args.rehearse_gloo else "nccl (RCCL)")),
-            "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "steps": len(batches) if strong else args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / max(1, len(batches)), 3),
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload + ("+lit" if lit else ""), "integrator": args.integrator,
                        "resolution": "%dx%d" % (W, H), "spp_per_step": spp,
@@ -348,6 +428,14 @@ def main():
             "rays_per_sample": round(job_rays / max(1.0, job_samples), 3),
             "shadow_rays_per_sample": round(st["shadow_rays"] / max(1, st["samples"]), 3), "lights": int(st["lights"]),
             "scene_load_s": round(load_s, 2),
+            # the timed region taken apart (max / min over ranks; per rank in rank order): rendering alone, then the one
+            # accumulation reduce -- export to the collective's buffer, RCCL reduce to rank 0, import and 1/N scale
+            "time_to_image_ms": round(elapsed * 1e3, 3),
+            "total_spp": args.total_spp if strong else None,
+            "render_ms": {"max": round(max(ranks_render), 3), "min": round(min(ranks_render), 3), "per_rank": [round(x, 3) for x in ranks_render]},
+            "reduce_ms": round(max(x[2] for x in per_rank), 3) if dist is not None else 0.0,
+            "scene_load_s_per_rank": [round(x[0], 2) for x in per_rank],
+            "spp_per_rank": [int(x[3]) for x in per_rank],
             "tail_launches": int(st["tail_launches"]),       # chunks of the timed region whose last bounces ran as one fused launch (short-path scenes)
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -56,6 +56,19 @@ def build_cli(force=False, verbose=False):
     return CLI
 
 
+def csrc_hash():
+    """sha256 (first 16 hex digits) over the kernel / ABI sources: stamped into profiles/traffic.json and valu.json by
+    tools/profile_round_summary.py and recomputed by bench.py, which drops counter-derived side fields that were
+    measured on other sources."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "ptx.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

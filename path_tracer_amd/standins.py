@@ -264,9 +264,27 @@ def make_spheres_bin(gltf_path, out_path):
     return dict(triangles=n_tris + 12, vertices=n_verts + 24)
 
 
+def make_sponza_rotated(gltf_path, out_path, degrees=30.0):
+    """The same scene with its one root node rotated about +Y (same .bin, same textures): every triangle of the
+    axis-aligned stand-in becomes oblique to the world axes, which loosens every box of the acceleration structure --
+    the `sponza_rot30_1080p` workload of bench.py."""
+    import json
+    import math
+    doc = json.load(open(gltf_path))
+    h = math.radians(degrees) * 0.5
+    for n in doc["nodes"]:
+        n["rotation"] = [0.0, math.sin(h), 0.0, math.cos(h)]
+    doc.setdefault("asset", {})["extras"] = {"note": "Sponza.gltf with its root node rotated %g degrees about +Y (path_tracer_amd/standins.py)" % degrees}
+    json.dump(doc, open(out_path, "w"))
+
+
 def ensure_standins(assets_dir):
     """Writes the missing .bin files next to their .gltf (idempotent).  Returns the paths written."""
     made = []
+    rot = os.path.join(assets_dir, "sponza", "Sponza_rot30.gltf")
+    if not os.path.exists(rot):
+        make_sponza_rotated(os.path.join(assets_dir, "sponza", "Sponza.gltf"), rot, 30.0)
+        made.append(rot)
     sp = os.path.join(assets_dir, "sponza", "Sponza.bin")
     if not os.path.exists(sp):
         make_sponza_bin(os.path.join(assets_dir, "sponza", "Sponza.gltf"), sp)

@@ -429,3 +429,42 @@ def test_bench_two_rank_rehearsal_reduce_leg():
     assert d["reduce_check"]["samples_per_rank"] == 4 and d["reduce_check"]["ranks"] == 2    # 2 dirty frames, then 4 accumulated
     assert d["reduce_check"]["rel_mse_vs_single_context"] < 1e-9, d["reduce_check"]
     assert d["value"] > 0 and d["steps"] == 2
+    # the line taken apart: per-rank render time, the reduce leg, per-rank load time
+    assert len(d["render_ms"]["per_rank"]) == 2 and d["render_ms"]["max"] >= d["render_ms"]["min"] > 0
+    assert d["reduce_ms"] > 0 and len(d["scene_load_s_per_rank"]) == 2 and d["spp_per_rank"] == [4, 4]
+    assert d["time_to_image_ms"] >= d["render_ms"]["max"]
+
+
+def test_bench_fixed_budget_mode_two_ranks_and_one(tmp_path):
+    """bench.py --total-spp S (BASELINE.json configs 3 / 5: a fixed sample budget partitioned over the GPUs): S = 10 spp
+    split over two ranks (5 each, as batches of 3 + 2), time-to-image including the reduce, "scaling": "strong"; the
+    combined image against one context rendering both slices.  Then the same budget at N = 1 through the same code.
+    Also the stale-profile guard: counter summaries stamped with another source hash are not quoted."""
+    import json
+    import subprocess
+    import sys
+    from helpers import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    stale = tmp_path / "traffic.json"
+    stale.write_text(json.dumps({"workload": "cornell_512", "csrc_sha16": "0000000000000000", "hbm_bytes_per_ray": 1.0, "tcc_hit_rate": 0.5}))
+    (tmp_path / "valu.json").write_text(json.dumps({"workload": "cornell_512", "csrc_sha16": "0000000000000000", "kernels": {}}))
+    lines = {}
+    for gpus in (2, 1):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", "cornell_512", "--total-spp", "10",
+               "--warmup", "1", "--spp-per-step", "3", "--max-depth", "8", "--cpu-baseline-spp", "0", "--traffic-json", str(stale)]
+        if gpus > 1:
+            cmd += ["--rehearse-gloo", "--verify-reduce"]
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        out = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(out) == 1, p.stdout
+        lines[gpus] = json.loads(out[0])
+    two, one = lines[2], lines[1]
+    assert two["scaling"] == one["scaling"] == "strong" and two["total_spp"] == one["total_spp"] == 10
+    assert two["spp_per_rank"] == [5, 5] and two["steps"] == 2 and one["spp_per_rank"] == [10] and one["steps"] == 4
+    # the job's samples: the budget x pixels, whatever the number of ranks
+    for d in (two, one):
+        assert round(d["value"] * d["time_to_image_ms"] * 1e-3) == 10 * 512 * 512, (d["value"], d["time_to_image_ms"])
+        assert d["roofline"]["profile_stale"] is True and d["roofline"]["traffic"] is None and d["roofline"]["valu_issue"] is None
+    assert two["reduce_ms"] > 0 and one["reduce_ms"] == 0.0
+    assert two["reduce_check"]["samples_per_rank"] == 5 and two["reduce_check"]["rel_mse_vs_single_context"] < 1e-9, two["reduce_check"]

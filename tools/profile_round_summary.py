@@ -2,7 +2,12 @@
 PMC sums per kernel, HBM traffic per ray (traffic.json) and VALU utilisation of the traversal / shading kernels (valu.json)."""
 import glob, json, os, subprocess, sys
 out, tag = sys.argv[1], sys.argv[2]
+integrator = sys.argv[3] if len(sys.argv) > 3 else "reference"
 here = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(here))
+from path_tracer_amd import build as B
+SRC_HASH = B.csrc_hash()
+WORKLOAD = "sponza_1080p" + ("+lit" if integrator == "lit" else "")
 trace = sorted(glob.glob(out + "/trace/**/*_kernel_trace.csv", recursive=True))[0]
 ts = json.loads(subprocess.check_output([sys.executable, os.path.join(here, "trace_summary.py"), trace, "2", "16"]))
 json.dump(ts, open(out + "/%s_kernel_trace_summary.json" % tag, "w"), indent=1)
@@ -10,7 +15,7 @@ stats = sorted(glob.glob(out + "/trace/**/*_kernel_stats.csv", recursive=True))[
 open(out + "/%s_kernel_stats.csv" % tag, "w").write(open(stats).read())
 pmc = json.loads(subprocess.check_output([sys.executable, os.path.join(here, "pmc_summary.py"), out]))
 json.dump(pmc, open(out + "/%s_pmc_summary.json" % tag, "w"), indent=1)
-EXT, SHD = "k_extend<false, false>", "k_shade"
+EXT, SHD = "k_extend<false, false>", ("k_shade_lit" if integrator == "lit" else "k_shade")
 # rays of the 2-spp PMC workload: printed by tools/prof_run.py into every pass log
 rays = None
 for f in glob.glob(out + "/pmc_*.log"):
@@ -20,7 +25,10 @@ for f in glob.glob(out + "/pmc_*.log"):
 e = pmc[EXT]
 fetch = e["FETCH_SIZE"]["sum"] * 1024 * 2
 write = e["WRITE_SIZE"]["sum"] * 1024
-traffic = {"workload": "sponza_1080p",
+sh = pmc.get(SHD, {})
+shade_hbm = ((sh["FETCH_SIZE"]["sum"] * 1024 * 2 + sh["WRITE_SIZE"]["sum"] * 1024) / rays) if "FETCH_SIZE" in sh and "WRITE_SIZE" in sh else None
+traffic = {"workload": WORKLOAD, "csrc_sha16": SRC_HASH,
+           "shade_kernel": SHD, "shade_hbm_bytes_per_ray": shade_hbm,
            "source": "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/prof_run.py 2 spp = %d rays over %d k_extend launches)" % (tag, rays, e["FETCH_SIZE"]["dispatches"]),
            "fetch_bytes_per_ray": fetch / rays, "write_bytes_per_ray": write / rays, "hbm_bytes_per_ray": (fetch + write) / rays,
            "tcc_hit_rate": e["TCC_HIT_sum"]["sum"] / max(1.0, e["TCC_HIT_sum"]["sum"] + e["TCC_MISS_sum"]["sum"]),
@@ -28,9 +36,9 @@ traffic = {"workload": "sponza_1080p",
 json.dump(traffic, open(out + "/traffic.json", "w"), indent=1)
 vp = json.loads(subprocess.check_output([sys.executable, os.path.join(here, "pmc_summary.py"), out + "/valu"]))
 # static instruction mix by issue class (tools/isa_mix.py, made where the library is built) and the measured issue costs
-mix_path = os.path.join(os.path.dirname(here), "profiles", "r02_isa_mix.json")
+mix_path = os.path.join(os.path.dirname(here), "profiles", "r03_isa_mix.json")
 static_mix = json.load(open(mix_path))["kernels"] if os.path.exists(mix_path) else {}
-valu = {"workload": "sponza_1080p",
+valu = {"workload": WORKLOAD, "csrc_sha16": SRC_HASH,
         "source": "rocprofv3 --pmc, two passes over tools/prof_run.py 16 (one 16-spp batch, the bench's launch size): SQ_WAVES SQ_WAVE_CYCLES "
                   "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY | SQ_INSTS_VALU "
                   "and its _FMA_F32 _ADD_F32 _MUL_F32 _CVT _INT32 _TRANS_F32 _INT64 breakdown; round tag %s" % tag,
@@ -41,11 +49,12 @@ valu = {"workload": "sponza_1080p",
                        "therefore reads up to 2.0 on full-rate code and is kept only as `active_x4_per_simd_cycle`.  "
                        "two_pipe_busy = SQ_INSTS_VALU x 4 / (2 pipes x 1024 SIMDs x cycles): share of ALL vector issue capacity in use (<= 1).  "
                        "half_rate_pipe_busy = half-rate instructions x 4 / (1024 x cycles) (<= 1): `_static_mix` prices SQ_INSTS_VALU with the "
-                       "kernel's static half-rate share (profiles/r02_isa_mix.json), `_lo` counts only conversions and transcendentals (x 2), `_hi` "
+                       "kernel's static half-rate share (profiles/r03_isa_mix.json), `_lo` counts only conversions and transcendentals (x 2), `_hi` "
                        "counts everything that is not an fp32 fma / add / mul.  residency = SQ_WAVE_CYCLES x 4 / (waves_per_simd x 1024 x cycles); "
                        "lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wait_mem / wait_issue = SQ_WAIT_ANY / SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES",
         "kernels": {}}
-for k, waves in ((EXT, 8), (SHD, 5)):   # resident waves per SIMD: k_extend 64 VGPRs, pinned to 8 by amdgpu_waves_per_eu; k_shade 89 VGPRs in 512-thread blocks -> 5
+# resident waves per SIMD: k_extend 64 VGPRs, pinned to 8 by amdgpu_waves_per_eu; k_shade ~100 VGPRs, k_shade_lit ~124, in 512-thread blocks: two blocks per CU = 4
+for k, waves in ((EXT, 8), (SHD, 4), ("k_extend<false, true>", 8)):
     if k not in vp:
         continue
     v = {c: d["sum"] for c, d in vp[k].items()}
