@@ -39,8 +39,14 @@ WORKLOADS = {
                                pos=[2.0, 0.25, 0.6], yaw=0.0, fov=70.0, res=(1920, 1080), geometry="real"),
     # deep incoherent paths through real, non-axis-aligned triangles: the two scanned meshes of the reference's app
     # (render_window.rs:412-426) inside a closed room (tools/make_room.py), camera inside: no path ends in the sky
+    # (further instances of the same two geometries -- ident dedup, geometry/mod.rs:62-65 -- fill the floor, so that a
+    # bounce meets scanned triangles about as often as a wall)
     "lion_boulder_room_1080p": dict(items=[("room/room.gltf", (0, 0, 0)), ("lion_head_2k/lion_head_2k.gltf", (2, 0, 0)),
-                                           ("boulder_01_2k/boulder_01_2k.gltf", (-2, 0, 0))],
+                                           ("boulder_01_2k/boulder_01_2k.gltf", (-2, 0, 0)),
+                                           ("boulder_01_2k/boulder_01_2k.gltf", (0.3, 0, -0.25)),
+                                           ("lion_head_2k/lion_head_2k.gltf", (1.35, 0, 0.55)), ("lion_head_2k/lion_head_2k.gltf", (1.5, 0, -0.7)),
+                                           ("lion_head_2k/lion_head_2k.gltf", (-0.85, 0, 0.95)), ("lion_head_2k/lion_head_2k.gltf", (0.75, 0, 0.95)),
+                                           ("lion_head_2k/lion_head_2k.gltf", (2.2, 0, 0.9))],
                                     pos=[0.3, 0.55, 1.45], yaw=0.0, fov=70.0, res=(1920, 1080), geometry="real (scanned meshes) in a generated closed room"),
     # the Sponza stand-in rotated 30 degrees about +Y with the camera rotated along: the same image content, every
     # triangle oblique to the world axes (looser boxes)

@@ -122,6 +122,7 @@ struct ptx_context {
     TexDesc *d_textures = nullptr;
     float *d_lut = nullptr;
     LitMaterial *d_lit_materials = nullptr;       // lit integrator
+    uint32_t n_dev_lit_materials = 0;             // rows in d_lit_materials (the material count at the last build)
     LightRec *d_lights = nullptr; float *d_light_cdf = nullptr; uint32_t n_lights = 0;
     uint32_t built_options = 0;                   // scene options the current device scene was built with
     void *staging = nullptr; uint64_t staging_bytes = 0;   // pinned host staging for scene uploads
@@ -560,12 +561,24 @@ int ptx_add_texture(ptx_context *c, const uint8_t *rgba8, uint32_t w, uint32_t h
     if (c->textures.size() + 1 > c->limits.max_textures)
         return fail(c, PTX_ERR_CAPACITY, "ptx_add_texture: bindless texture pool size exceeded"); // renderer.rs:899-901
     if (int r = bind(c)) return r;
+    // device layout: tiles of 8 x 4 texels, one cache line each (TexDesc)
+    const uint32_t tiles_x = (w + kTexTileW - 1u) / kTexTileW, tiles_y = (h + kTexTileH - 1u) / kTexTileH;
+    if ((uint64_t)tiles_x * tiles_y * 32ull > 0xFFFFFFFFull) return fail(c, PTX_ERR_INVALID, "ptx_add_texture: more than 2^32 texels");
+    std::vector<uint32_t> tiled((size_t)tiles_x * tiles_y * 32u, 0u);
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(rgba8) + (size_t)y * w;   // (memcpy below: rgba8 need not be 4-byte aligned)
+        for (uint32_t x = 0; x < w; ++x) {
+            uint32_t px;
+            memcpy(&px, reinterpret_cast<const uint8_t *>(row) + (size_t)x * 4u, 4);
+            tiled[((size_t)(y >> 2) * tiles_x + (x >> 3)) * 32u + ((y & 3u) << 3) + (x & 7u)] = px;
+        }
+    }
     void *d = nullptr;
-    uint64_t bytes = (uint64_t)w * h * 4;
+    uint64_t bytes = (uint64_t)tiled.size() * 4;
     HIP_TRY(c, hipMalloc(&d, bytes));
-    hipError_t e = hipMemcpy(d, rgba8, bytes, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpy(d, tiled.data(), bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d); return fail(c, PTX_ERR_HIP, std::string("ptx_add_texture: ") + hipGetErrorString(e)); }
-    TexDesc t; t.texels = (const uint8_t *)d; t.width = w; t.height = h; t._pad = 0;
+    TexDesc t; t.texels = (const uint8_t *)d; t.width = w; t.height = h; t.tiles_x = tiles_x;
     t.srgb = (uint32_t)srgb & (uint32_t)(PTX_TEXTURE_SRGB | PTX_TEXTURE_REPEAT | PTX_TEXTURE_LINEAR);
     *index = (uint32_t)c->textures.size();
     c->textures.push_back(t);
@@ -879,7 +892,7 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
     if (int r = sync_all(c)) return r;
     lap("sync");
     dfree(c->d_lit_materials); dfree(c->d_lights); dfree(c->d_light_cdf);
-    c->n_lights = 0;
+    c->n_lights = 0; c->n_dev_lit_materials = 0;
     c->scene_ready = false;
     c->n_nodes = (uint32_t)bvh.nodes.size(); c->n_tris = nt; c->bvh_depth = bvh.depth;
     // device buffers are kept across rebuilds / refits while they are large enough
@@ -911,6 +924,7 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
     if (!lit_materials.empty()) {
         HIP_TRY(c, hipMalloc((void **)&c->d_lit_materials, lit_materials.size() * sizeof(LitMaterial)));
         HIP_TRY(c, hipMemcpy(c->d_lit_materials, lit_materials.data(), lit_materials.size() * sizeof(LitMaterial), hipMemcpyHostToDevice));
+        c->n_dev_lit_materials = (uint32_t)lit_materials.size();
     }
     if (!lights.empty()) {
         HIP_TRY(c, hipMalloc((void **)&c->d_lights, lights.size() * sizeof(LightRec)));
@@ -1003,7 +1017,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
     if (chunk * npix > 0xFFFFFF00ull) chunk = 0xFFFFFF00ull / npix;
 
     SceneDev sc;
-    sc.lit_materials = c->d_lit_materials; sc.lights = c->d_lights; sc.light_cdf = c->d_light_cdf; sc.n_lights = c->n_lights;
+    sc.lit_materials = c->d_lit_materials; sc.n_lit_materials = c->n_dev_lit_materials; sc.lights = c->d_lights; sc.light_cdf = c->d_light_cdf; sc.n_lights = c->n_lights;
     sc.nodes = c->d_nodes; sc.n_nodes = c->n_nodes; sc.tris = c->d_tris; sc.shade = c->d_shade; sc.tri_of_rank = c->d_tri_of_rank;
     sc.textures = c->d_textures; sc.n_textures = c->n_dev_textures; sc.srgb_lut = c->d_lut;
     ImagesDev img; img.albedo = c->d_albedo; img.normal = c->d_normal; img.depth = c->d_depth; img.ids = c->d_ids;
@@ -1150,7 +1164,7 @@ int ptx_render_static(ptx_context *c, const ptx_uniforms *u, const ptx_camera *c
     const uint32_t n_paths = (uint32_t)npix;
 
     SceneDev sc;
-    sc.lit_materials = c->d_lit_materials; sc.lights = c->d_lights; sc.light_cdf = c->d_light_cdf; sc.n_lights = c->n_lights;
+    sc.lit_materials = c->d_lit_materials; sc.n_lit_materials = c->n_dev_lit_materials; sc.lights = c->d_lights; sc.light_cdf = c->d_light_cdf; sc.n_lights = c->n_lights;
     sc.nodes = c->d_nodes; sc.n_nodes = c->n_nodes; sc.tris = c->d_tris; sc.shade = c->d_shade; sc.tri_of_rank = c->d_tri_of_rank;
     sc.textures = c->d_textures; sc.n_textures = c->n_dev_textures; sc.srgb_lut = c->d_lut;
     ImagesDev img; img.albedo = c->d_albedo; img.normal = c->d_normal; img.depth = c->d_depth; img.ids = c->d_ids;

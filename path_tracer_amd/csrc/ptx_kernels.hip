@@ -479,7 +479,9 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
 // ---------------------------------------------------------------- shade
 __device__ __forceinline__ f3 texel_at(const TexDesc &tx, const float *lut, uint32_t x, uint32_t y)
 {
-    uint32_t texel = *reinterpret_cast<const uint32_t *>(tx.texels + ((uint64_t)y * tx.width + x) * 4u);
+    // texels are stored in tiles of 8 x 4 (one 128-byte line, see TexDesc): same texel, other address
+    const uint32_t at = ((y >> 2) * tx.tiles_x + (x >> 3)) * 32u + ((y & 3u) << 3) + (x & 7u);
+    uint32_t texel = *reinterpret_cast<const uint32_t *>(tx.texels + (uint64_t)at * 4u);
     uint32_t r = texel & 0xFFu, g = (texel >> 8) & 0xFFu, b = (texel >> 16) & 0xFFu;
     if (tx.srgb & 1u) return mk3(lut[r], lut[g], lut[b]);
     return mk3((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f);
@@ -871,6 +873,8 @@ __device__ __forceinline__ uint32_t block_reserve(bool flag, const BlockScan &bs
 // (its occlusion ray comes back in q0 .. q2), BSDF sampling, Russian roulette.  Shared by the wavefront stage (k_shade_lit)
 // and the fused tail (k_tail_lit): one set of expression trees, so both give the oracle's bits.
 constexpr uint32_t kLdsCdf = 4096;          // entries of k_shade_lit's LDS light table (16 KB)
+constexpr uint32_t kLdsLitMaterials = 128;  // rows of SceneDev::lit_materials k_shade_lit keeps in LDS (6 KB): the row index comes out of the
+                                            // triangle's record, so a global fetch of it is one more dependent round trip per hit
 struct LitState {
     f3 thr, add, gb_normal, new_o, new_d;
     float gb_dist, next_pdf;
@@ -880,7 +884,7 @@ struct LitState {
 };
 __device__ __forceinline__ void lit_shade_hit(const SceneDev &sc, const FrameDev &f, const TexDesc *s_tex, const float *s_lut,
                                               uint32_t depth, f3 o, f3 dir, uint32_t uv_state, uint32_t rng_acc, float prev_pdf,
-                                              float hit_t, float path_bits, bool want_ids, const float *lds_cdf, uint32_t cdf_stride,
+                                              float hit_t, float path_bits, bool want_ids, const float *lds_cdf, uint32_t cdf_stride, const LitMaterial *lds_lm,
                                               const float4 &t0, const float4 &t1, const float4 &t2, const float4 &s0,
                                               const float4 &s1, const float4 &s2, const float4 &s3, const float4 &s4, LitState &S)
 {
@@ -903,7 +907,8 @@ __device__ __forceinline__ void lit_shade_hit(const SceneDev &sc, const FrameDev
     const float tu = (s2.y * bx + s2.w * by) + s3.y * bz;
     const float tv = (s2.z * bx + s3.x * by) + s3.z * bz;
     const f3 P = o + dir * hit_t;
-    const LitMaterial lm = sc.lit_materials[__float_as_uint(s4.w)];
+    const uint32_t lm_row = __float_as_uint(s4.w);
+    const LitMaterial lm = (lds_lm && lm_row < kLdsLitMaterials) ? lds_lm[lm_row] : sc.lit_materials[lm_row];
     f3 albedo = mk3(t2.w, s3.w, s4.x);
     const uint32_t tex = __float_as_uint(t0.w);
     if (tex != 0xFFFFFFFFu) {
@@ -1112,6 +1117,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
     __shared__ uint32_t s_cnt[kShadeBlock / 64];
     __shared__ uint32_t s_base, s_hits;
     __shared__ float s_cdf[kLdsCdf];        // light pick: last CDF value of every cdf_stride lights (see lit_shade_hit)
+    __shared__ LitMaterial s_lm[kLdsLitMaterials];
 
     // capped grid, tiles of kShadeBlock rays (see k_shade)
     const uint32_t n_live = counters[depth];
@@ -1127,6 +1133,9 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
         const uint32_t nw = (sc.n_textures < kLdsTextures ? sc.n_textures : kLdsTextures) * (uint32_t)(sizeof(TexDesc) / 4);
         for (uint32_t w = threadIdx.x; w < nw; w += kShadeBlock)
             reinterpret_cast<uint32_t *>(s_tex)[w] = reinterpret_cast<const uint32_t *>(sc.textures)[w];
+        const uint32_t nm = (sc.n_lit_materials < kLdsLitMaterials ? sc.n_lit_materials : kLdsLitMaterials) * (uint32_t)(sizeof(LitMaterial) / 4);
+        for (uint32_t w = threadIdx.x; w < nm; w += kShadeBlock)
+            reinterpret_cast<uint32_t *>(s_lm)[w] = reinterpret_cast<const uint32_t *>(sc.lit_materials)[w];
     }
     // The next tile's ray + hit are fetched behind this tile's shading, in front of its two queue reservations (two atomic
     // round trips, five barriers): one of a tile's dependent round trips leaves the critical path, and no register is
@@ -1179,7 +1188,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev
             S.done = true;
         } else {
             lit_shade_hit(sc, f, s_tex, s_lut, depth, o, dir, uv_state, rng_acc, prev_pdf, hr.x, r0.w, depth == 0 && sample == f.ids_sample,
-                          sc.n_lights ? s_cdf : nullptr, cdf_stride, t0, t1, t2, s0, s1, s2, s3, s4, S);
+                          sc.n_lights ? s_cdf : nullptr, cdf_stride, s_lm, t0, t1, t2, s0, s1, s2, s3, s4, S);
         }
 
         was_hit = S.was_hit; want_shadow = S.want_shadow;
@@ -1293,7 +1302,7 @@ __global__ void __launch_bounds__(64) k_tail_lit(SceneDev sc, FrameDev f, uint32
                     const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri);
                     const float4 t0 = sp[0], t1 = sp[1], t2 = sp[2], s0 = sp[3], s1 = sp[4], s2 = sp[5], s3 = sp[6], s4 = sp[7];
                     lit_shade_hit(sc, f, s_tex, s_lut, depth, o, dir, uv_state, rng_acc, prev_pdf, tr.hit.t, path_bits, false,
-                                  nullptr, 1u, t0, t1, t2, s0, s1, s2, s3, s4, S);
+                                  nullptr, 1u, nullptr, t0, t1, t2, s0, s1, s2, s3, s4, S);
                 }
                 if (S.have_add) { L.x = L.x + S.add.x; L.y = L.y + S.add.y; L.z = L.z + S.add.z; }
             }
