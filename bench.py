@@ -294,6 +294,11 @@ def main():
         divergence = dict(node_block_lanes=round(ws[2] / max(1, ws[1]) / 64.0, 4), tri_block_lanes=round(ws[4] / max(1, ws[3]) / 64.0, 4),
                           node_blocks_per_iteration=round(ws[1] / max(1, ws[0]), 4), tri_blocks_per_iteration=round(ws[3] / max(1, ws[0]), 4),
                           source="instrumented k_extend<stats> on one untimed step of the same workload")
+        ea = ist["extend_append"]
+        wave_counters = dict(rays=int(ist["rays"]), waves=int(st["extend_launches"] and ctx.get_option(capi.OPTION_EXTEND_WAVES)) * 16,
+                             iterations=int(ws[0]), node_blocks=int(ws[1]), node_lanes=int(ws[2]), tri_blocks=int(ws[3]), tri_lanes=int(ws[4]),
+                             refills=int(ws[5]), append_blocks=int(ea[0]), append_passes=int(ea[1]), refill_passes=int(ea[2]),
+                             source="instrumented k_extend<stats>, one untimed step (16 launches of the reference integrator): the weights of tools/isa_budget.py")
         ph = ist["extend_phase_cycles"]
         ph_tot = float(sum(ph)) or 1.0
         phases = {n: round(c / ph_tot, 4) for n, c in zip(PHASE_NAMES, ph)}
@@ -374,7 +379,7 @@ def main():
                         tris_per_ray=round(tris_per_ray, 2), rays_per_launch=round(rays_per_launch, 1),
                         avg_launch_ms=round(avg_launch_s * 1e3, 4), launches=int(launches),
                         extend_ms=round(st["extend_ms"], 2),
-                        valu_issue=valu, hbm=hbm, l2=l2, divergence=divergence, wave_lifetime_by_phase=phases,
+                        valu_issue=valu, hbm=hbm, l2=l2, divergence=divergence, wave_lifetime_by_phase=phases, wave_counters=wave_counters,
                         note="bound = vector ALU: `frac` prices SURVEY 8d's algorithmic lane-ops (112 per node visit, 60 per triangle "
                              "test; 1 lane-op = 1 FMA slot = 2 FLOP) against the 157.3 TFLOP/s fp32 vector peak.  The instructions the "
                              "kernel really issues, priced with the per-class issue costs measured on this chip "

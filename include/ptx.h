@@ -170,6 +170,8 @@ typedef struct {
     uint64_t extend_phase_cycles[8];       /* level 2: shader cycles of wave lifetime per phase of the traversal kernel, summed over waves: ray
                                               fetch, node-load wait, node test + pick, triangle-queue append, triangle fetch wait, triangle
                                               test, hand-back of the hits, retire + loop control */
+    uint64_t extend_append[3];             /* level 2: wave iterations that queued leaf triangles, passes of the per-lane queue-write loop in them,
+                                              ray-fetch passes of the refills -- the weights tools/isa_budget.py prices the kernel's blocks with */
 } ptx_stats;
 
 typedef struct ptx_context ptx_context;

@@ -69,7 +69,8 @@ class Stats(C.Structure):
                 ("bvh_bytes", C.c_uint64), ("bvh_depth", C.c_uint32), ("_pad", C.c_uint32),
                 ("nodes_fetched", C.c_uint64), ("tris_tested", C.c_uint64), ("wave_sched", C.c_uint64 * 6),
                 ("shadow_rays", C.c_uint64), ("lights", C.c_uint64), ("bvh_builds", C.c_uint64), ("bvh_refits", C.c_uint64),
-                ("bvh_device_refits", C.c_uint64), ("tail_launches", C.c_uint64), ("extend_phase_cycles", C.c_uint64 * 8)]
+                ("bvh_device_refits", C.c_uint64), ("tail_launches", C.c_uint64), ("extend_phase_cycles", C.c_uint64 * 8),
+                ("extend_append", C.c_uint64 * 3)]
 
 
 EXPORTS = [
@@ -290,6 +291,7 @@ class Context:
         d = {k: getattr(s, k) for k, _ in Stats._fields_ if not k.startswith("_")}
         d["wave_sched"] = list(d["wave_sched"])
         d["extend_phase_cycles"] = list(d["extend_phase_cycles"])
+        d["extend_append"] = list(d["extend_append"])
         return d
 
     def reset_stats(self):

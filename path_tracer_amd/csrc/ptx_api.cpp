@@ -1365,6 +1365,7 @@ int ptx_get_stats(ptx_context *c, ptx_stats *s)
     s->bvh_depth = c->bvh_depth;
     s->shadow_rays = t[11]; s->lights = c->n_lights;
     for (int i = 0; i < 8; ++i) s->extend_phase_cycles[i] = t[12 + i];
+    for (int i = 0; i < 3; ++i) s->extend_append[i] = t[20 + i];
     s->bvh_builds = c->n_builds; s->bvh_refits = c->n_refits; s->bvh_device_refits = c->n_device_refits;
     s->tail_launches = c->n_tail_launches;
     return PTX_OK;

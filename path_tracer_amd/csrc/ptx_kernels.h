@@ -176,7 +176,7 @@ uint32_t default_shade_grid();      // PTX_SHADE_GRID or 8192
 void launch_resolve(hipStream_t s, const FrameDev &f, const ImagesDev &img, const float4 *results, uint32_t n_samples);
 void launch_accumulate_stats(hipStream_t s, const uint32_t *counters, uint32_t max_depth, uint64_t n_samples,
                              uint64_t *totals);
-constexpr int kNumTotals = 20;   // rays, hits, samples, nodes, tris, 6 x wave_sched, shadow rays, 8 x traversal phase cycles
+constexpr int kNumTotals = 23;   // rays, hits, samples, nodes, tris, 6 x wave_sched, shadow rays, 8 x traversal phase cycles, append blocks / append loop passes / refill passes
 void launch_scale_copy(hipStream_t s, const float4 *src, float4 *dst, uint64_t n, float scale);
 
 // ---- device refit (ptx_refit.hip): instance motion without a host round trip

@@ -117,6 +117,13 @@ struct LaneStack {
     __device__ __forceinline__ bool empty() const { return sp == 0; }
 };
 
+// wave-wide maximum (instrumented build only): every lane ends up with the value of lane 63 after an inclusive max scan
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64); v = o > v ? o : v; }
+    return v;
+}
+
 // __ballot() takes an int: the bool is widened and compared again (v_cndmask + v_cmp per call in the traversal loop)
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
@@ -255,6 +262,9 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
         }                                                                                \
     } while (0)
     unsigned long long w_iters = 0, w_node_blocks = 0, w_node_lanes = 0, w_tri_blocks = 0, w_tri_lanes = 0, w_refills = 0;
+    unsigned long long w_append_blocks = 0, w_append_passes = 0, w_refill_passes = 0;
+    // The "[phase: ...]" comments below are read by tools/isa_budget.py: with the line table of the compiled kernel they
+    // assign every instruction of the loop to a phase, and the counters of the instrumented build weight the phases.
     uint32_t chunk_next = 0, chunk_end = 0;
     // Rays are handed out in chunks, one atomic each.  A single word takes ~88 M atomics/s, so a long queue of cheap
     // rays (33 M primary rays that mostly miss: 260 k chunks of 128) is bound by that rate alone -- 3.1 ms measured
@@ -278,6 +288,7 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
     bool exhausted = (uint64_t)(blockIdx.x / kFetchHeads) * chunk >= seg || n == 0;
 
     for (;;) {
+        // [phase: refill]
         unsigned long long idle = ballot64(next_ni == kIdle);
         if (!exhausted && __popcll(idle) >= sched.refill) {
             if (kStats) w_refills++;
@@ -293,6 +304,7 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
             if (!kAnyHit && pending && old_tri != 0xFFFFFFFFu) old_tri = sc.tri_of_rank[old_tri];
             if (pending) ray = kNoRay;
             for (int pass = 0; pass < 2 && idle != 0ull; ++pass) {
+                if (kStats) w_refill_passes++;
                 if (chunk_next == chunk_end) {
                     bool got = false;
                     while (dead != (1u << kFetchHeads) - 1u) {
@@ -345,6 +357,7 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
         }
         const int stop_at = exhausted ? 0 : (64 - sched.refill);
         do {
+            // [phase: node]
             // ---- node visits: every lane whose walk is not finished and whose last leaf hits are queued
             // (a ballot per comparison, combined as scalars: the ballot of a conjunction is widened to a VGPR and compared
             // again, v_cndmask + v_cmp, because the compiler cannot see that the AND of two v_cmp results lies inside EXEC)
@@ -366,9 +379,11 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                 tr.node_eval(load_node(sc.nodes, next_ni));
                 next_ni = advance_walk(tr, st);
             }
+            // [phase: append]
             // ---- queue the triangles of the leaves just hit: wave prefix sum of the per-lane counts
             //      (six DPP adds), then every lane writes its own run of the FIFO
             if (ballot64(tr.tg_mask != 0) != 0ull) {
+                if (kStats) w_append_blocks++;
                 const uint32_t room = kTriQueue - (q_tail - q_head);
                 const uint32_t cnt = (uint32_t)__popc(tr.tg_mask);
                 const uint32_t incl = wave_inclusive_sum(cnt);
@@ -381,15 +396,19 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                     uint32_t pos = q_tail + incl - cnt;
                     my_tail = q_tail + incl;
                     do {
+                        // [phase: append-loop]
                         uint32_t ti = tr.tri_pick();
                         uint32_t idx = pos & (kTriQueue - 1u);
                         s_qtri[idx] = ti | (lane_id << kTriIndexBits);
                         ++pos;
                     } while (tr.tg_mask != 0);
                 }
+                // [phase: append]
+                if (kStats) w_append_passes += (unsigned long long)__builtin_amdgcn_readfirstlane((int)wave_max_u32(fits ? cnt : 0u));
                 q_tail += total;
             }
             PTX_PHASE(3);
+            // [phase: tri-decision]
             // ---- triangle tests, a full wave's worth at a time
             {
                 const uint32_t qn = q_tail - q_head;
@@ -397,6 +416,7 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                 const int n_wait = __popcll(ballot64(next_ni == kWalked) & m_no_tris & ballot64((int)(q_head - my_tail) < 0));
                 const int n_node = __popcll(ballot64(next_ni < kIdle) & m_no_tris);
                 if (qn >= (uint32_t)sched.tri_min || (qn > 0u && (n_wait >= sched.flush_min || n_node == 0))) {
+                    // [phase: tri-block]
                     wave_lds_sync();
                     const uint32_t nt = qn < 64u ? qn : 64u;
                     if (kStats) { w_tri_blocks++; w_tri_lanes += nt; }
@@ -450,6 +470,7 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                     PTX_PHASE(6);
                 }
             }
+            // [phase: retire]
             // ---- rays whose walk is over and whose pairs have all been tested
             {
                 const bool retire = next_ni == kWalked && tr.tg_mask == 0 && (int)(q_head - my_tail) >= 0;
@@ -471,6 +492,7 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
             atomicAdd(&trav_totals[2], w_iters); atomicAdd(&trav_totals[3], w_node_blocks); atomicAdd(&trav_totals[4], w_node_lanes);
             atomicAdd(&trav_totals[5], w_tri_blocks); atomicAdd(&trav_totals[6], w_tri_lanes); atomicAdd(&trav_totals[7], w_refills);
             for (int i = 0; i < 8; ++i) atomicAdd(&trav_totals[9 + i], ph[i]);      // totals[12 + i]: trav_totals = totals + 3
+            atomicAdd(&trav_totals[17], w_append_blocks); atomicAdd(&trav_totals[18], w_append_passes); atomicAdd(&trav_totals[19], w_refill_passes);
         }
 #undef PTX_PHASE
     }
