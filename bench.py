@@ -295,7 +295,7 @@ def main():
                           node_blocks_per_iteration=round(ws[1] / max(1, ws[0]), 4), tri_blocks_per_iteration=round(ws[3] / max(1, ws[0]), 4),
                           source="instrumented k_extend<stats> on one untimed step of the same workload")
         ea = ist["extend_append"]
-        wave_counters = dict(rays=int(ist["rays"]), waves=int(st["extend_launches"] and ctx.get_option(capi.OPTION_EXTEND_WAVES)) * 16,
+        wave_counters = dict(rays=int(ist["rays"]), waves=int(ctx.get_option(capi.OPTION_EXTEND_WAVES)) * args.max_depth,
                              iterations=int(ws[0]), node_blocks=int(ws[1]), node_lanes=int(ws[2]), tri_blocks=int(ws[3]), tri_lanes=int(ws[4]),
                              refills=int(ws[5]), append_blocks=int(ea[0]), append_passes=int(ea[1]), refill_passes=int(ea[2]),
                              source="instrumented k_extend<stats>, one untimed step (16 launches of the reference integrator): the weights of tools/isa_budget.py")

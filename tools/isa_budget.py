@@ -25,7 +25,7 @@ src = os.path.join(B.CSRC, "ptx_kernels.hip")
 text_src = open(src).read().splitlines()
 k_lo = next(i for i, l in enumerate(text_src) if l.startswith("k_extend(SceneDev sc")) + 1
 k_hi = next(i for i, l in enumerate(text_src) if i > k_lo and l.startswith("// ---------------------------------------------------------------- shade")) + 1
-markers = [(i + 1, re.search(r"\[phase: ([\w-]+)\]", l).group(1)) for i, l in enumerate(text_src) if "[phase:" in l and k_lo <= i + 1 <= k_hi]
+markers = [(i + 1, m.group(1)) for i, l in enumerate(text_src) for m in [re.search(r"\[phase: ([\w-]+)\]", l)] if m and k_lo <= i + 1 <= k_hi]
 trav = open(os.path.join(B.CSRC, "traverse.h")).read().splitlines()
 def fn_range(name):
     a = next(i for i, l in enumerate(trav) if re.search(r"\b%s\(" % name, l) and ("PT_HD" in l or "__device__" in l)) + 1
