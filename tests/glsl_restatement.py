@@ -14,7 +14,15 @@ again, in numpy float32, sharing NO code with the oracle or the product:
 Deliberately different where the reference leaves the arithmetic to its driver or its maths crate: its own glTF
 reader, float64 matrix inverses (glam inverts in fp32), numpy's sin / cos (the oracle pins a polynomial), and a
 Moeller-Trumbore triangle test, brute force over all triangles (the oracle uses edge functions and a BVH).  So the
-two agree to rounding, not bit for bit; tests/test_oracle_cpu.py states the tolerances.  Untextured scenes only.
+two agree to rounding, not bit for bit; tests/test_oracle_cpu.py states the tolerances.
+
+Textures (round 3): base-colour textures are sampled the way the reference's descriptors make the hardware sample them --
+rchit.glsl:192-198 `texture(textures[idx], uv).xyz` with the factor dropped; graphics.rs:453-459 SamplerCreateInfo::default()
+= nearest, clamp-to-edge, LOD 0; graphics.rs:492-516 8-bit colour -> R8G8B8A8_SRGB, i.e. the IEC 61966-2-1 decode on
+fetch -- written here from those lines and the Vulkan rules for unnormalised texel coordinates (floor(u * W), clamped),
+with the decode evaluated in float64 per texel (the oracle and the kernels read a 256-entry fp32 table).  The decoded
+8-bit texels themselves are an INPUT (`decode`): which JPEG decoder produced them is a third-party boundary of its own
+(image 0.25.6 / zune-jpeg in the reference), not something a restatement of the shaders can arbitrate.
 """
 import json
 import os
@@ -32,9 +40,11 @@ def _quat_to_mat3(q):
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
-def load_gltf(path):
+def load_gltf(path, offset=(0.0, 0.0, 0.0), decode=None):
     """Root nodes with a mesh only (gltf.rs:32-34), one entity per primitive: world-space triangle vertices,
-    OBJECT-space vertex normals (rchit.glsl:175-179 never transforms them), material (base colour, roughness)."""
+    OBJECT-space vertex normals (rchit.glsl:175-179 never transforms them), material (base colour, roughness, and the
+    base-colour texture's RGBA8 texels if it has one: material.rs:43-68).  `offset` is added to the node translation
+    (gltf.rs:36-44); `decode(path) -> HxWx{3,4} uint8` decodes an image file."""
     doc = json.load(open(path))
     base = os.path.dirname(path)
     blobs = [open(os.path.join(base, b["uri"]), "rb").read() for b in doc["buffers"]]
@@ -50,14 +60,14 @@ def load_gltf(path):
         rows = [struct.unpack_from("<%d%s" % (ncomp, fmt), raw, off + k * stride) for k in range(a["count"])]
         return np.array(rows)
 
-    tris, nrms, inst, prim, mats = [], [], [], [], []
+    tris, nrms, uvs, inst, prim, mats = [], [], [], [], [], []
     entity = 0
     scene = doc["scenes"][doc.get("scene", 0)]
     for ni in scene["nodes"]:
         node = doc["nodes"][ni]
         if "mesh" not in node:
             continue
-        T = np.array(node.get("translation", [0, 0, 0]), float)
+        T = np.array(node.get("translation", [0, 0, 0]), float) + np.array(offset, float)
         R = _quat_to_mat3(node.get("rotation", [0, 0, 0, 1]))
         S = np.array(node.get("scale", [1, 1, 1]), float)
         M = (R * S[None, :]).astype(F)                    # Mat4::from_scale_rotation_translation, upper 3x3, as fp32
@@ -67,13 +77,43 @@ def load_gltf(path):
             nrm = accessor(p["attributes"]["NORMAL"]).astype(F)
             idx = accessor(p["indices"]).astype(np.int64).reshape(-1, 3) if "indices" in p else np.arange(len(pos)).reshape(-1, 3)
             m = doc["materials"][p["material"]].get("pbrMetallicRoughness", {}) if "material" in p else {}
-            assert "baseColorTexture" not in m, "untextured scenes only"
+            tex = None
+            if "baseColorTexture" in m:
+                img = doc["images"][doc["textures"][m["baseColorTexture"]["index"]]["source"]]
+                px = np.asarray(decode(os.path.join(base, img["uri"])))
+                if px.shape[2] == 3:                      # graphics.rs:507-516: RGB8 is padded to RGBA8 with alpha 255
+                    px = np.concatenate([px, np.full(px.shape[:2] + (1,), 255, np.uint8)], 2)
+                tex = px
+            tuv = accessor(p["attributes"]["TEXCOORD_0"]).astype(F) if "TEXCOORD_0" in p["attributes"] else np.zeros((len(pos), 2), F)
             world = (pos @ M.T + Tf).astype(F)            # as_instance transform applied by the acceleration structure
-            for k, (a, b, c) in enumerate(idx):
-                tris.append(world[[a, b, c]]); nrms.append(nrm[[a, b, c]]); inst.append(entity); prim.append(k)
-            mats.append((np.array(m.get("baseColorFactor", [1, 1, 1, 1])[:3], F), F(m.get("roughnessFactor", 1.0))))
+            tris.append(world[idx]); nrms.append(nrm[idx]); uvs.append(tuv[idx])
+            inst.append(np.full(len(idx), entity)); prim.append(np.arange(len(idx)))
+            mats.append((np.array(m.get("baseColorFactor", [1, 1, 1, 1])[:3], F), F(m.get("roughnessFactor", 1.0)), tex))
             entity += 1
-    return dict(tris=np.array(tris, F), nrms=np.array(nrms, F), inst=np.array(inst), prim=np.array(prim), mats=mats)
+    return dict(tris=np.concatenate(tris).astype(F), nrms=np.concatenate(nrms).astype(F), uvs=np.concatenate(uvs).astype(F),
+                inst=np.concatenate(inst), prim=np.concatenate(prim), mats=mats)
+
+
+def merge(*scenes):
+    """Several imports into one scene, entity indices continuing (Scene::import_gltf called once per file)."""
+    out = dict(tris=[], nrms=[], uvs=[], inst=[], prim=[], mats=[])
+    for sc in scenes:
+        out["inst"].append(sc["inst"] + len(out["mats"]))
+        for k in ("tris", "nrms", "uvs", "prim"):
+            out[k].append(sc[k])
+        out["mats"] += sc["mats"]
+    return {k: (np.concatenate(v) if k != "mats" else v) for k, v in out.items()}
+
+
+def _texture(tex, uv):
+    """texture(sampler2D, uv).xyz through VkSamplerCreateInfo defaults (nearest, clamp to edge, LOD 0) on an
+    R8G8B8A8_SRGB image: texel (floor(u W), floor(v H)) clamped into the image, sRGB -> linear on fetch."""
+    h, w = tex.shape[:2]
+    x = np.clip(np.floor(uv[:, 0].astype(F) * F(w)), 0, w - 1).astype(np.int64)
+    y = np.clip(np.floor(uv[:, 1].astype(F) * F(h)), 0, h - 1).astype(np.int64)
+    c = tex[y, x, :3].astype(np.float64) / 255.0
+    lin = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+    return lin.astype(F)
 
 
 def camera(pos, yaw_deg, fov_deg, aspect, near, far):
@@ -121,6 +161,10 @@ def _cosine_hemisphere(uv, depth, acc, seed, n):
 
 def _trace(sc, o, d, tmin, tmax):
     """closest hit of each ray over all triangles (Moeller-Trumbore, both faces); ties -> lowest (instance, primitive)"""
+    if len(o) * len(sc["tris"]) > (1 << 22):                        # bounded temporaries: a block of rays at a time
+        step = max(1, (1 << 22) // len(sc["tris"]))
+        parts = [_trace(sc, o[i:i + step], d[i:i + step], tmin, tmax) for i in range(0, len(o), step)]
+        return tuple(np.concatenate([p[k] for p in parts]) for k in range(5))
     v0, e1, e2 = sc["tris"][:, 0][None], (sc["tris"][:, 1] - sc["tris"][:, 0])[None], (sc["tris"][:, 2] - sc["tris"][:, 0])[None]
     D, O = d[:, None, :], o[:, None, :]
     p = np.cross(D, e2); det = np.sum(e1 * p, -1)
@@ -177,6 +221,11 @@ def render(sc, view_inv, proj_inv, W, H, spp, seed, max_depth=16, z_near=0.1, z_
                 rd, ro = d[idx][h], o[idx][h]
                 wp = (ro + rd * t[h][:, None]).astype(F)
                 base = np.array([sc["mats"][i][0] for i in sc["inst"][tr]], F)
+                tuv = (sc["uvs"][tr, 0] * b0[:, None] + sc["uvs"][tr, 1] * bu[h][:, None] + sc["uvs"][tr, 2] * bv[h][:, None]).astype(F)
+                for e in np.unique(sc["inst"][tr]):                # rchit.glsl:192-198: the texel replaces the factor
+                    if sc["mats"][e][2] is not None:
+                        sel = sc["inst"][tr] == e
+                        base[sel] = _texture(sc["mats"][e][2], tuv[sel])
                 rough = np.array([sc["mats"][i][1] for i in sc["inst"][tr]], F)
                 refl = (rd - F(2) * np.sum(N * rd, 1, dtype=F)[:, None] * N).astype(F)
                 rr = _normalize(_cosine_hemisphere(uv[idx][h], depth, acc, seed, N))
