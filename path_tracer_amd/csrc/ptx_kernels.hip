@@ -161,6 +161,7 @@ __device__ __forceinline__ uint32_t advance_walk(Trav &tr, LaneStack &st)
 struct ExtendSched {
     int refill, tri_min, flush_min; uint32_t chunk, chunk_grow;
     uint32_t primary;       // camera rays: origin = cam_o, path index = queue index (k_raygen stores neither)
+    uint32_t seed_t;        // PTX_LAB_SEED builds only (tools/lab/seed_bound.sh): start every ray with the closest t of a previous pass
     float cam_o[3];
 };
 
@@ -343,6 +344,15 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
                     s_dir[0][lane_id] = r1.x; s_dir[1][lane_id] = r1.y; s_dir[2][lane_id] = r1.z;
                     s_org[0][lane_id] = r0.x; s_org[1][lane_id] = r0.y; s_org[2][lane_id] = r0.z;
                     s_best[lane_id] = ((unsigned long long)__float_as_uint(t_max) << 32) | 0xFFFFFFFFull;
+#ifdef PTX_LAB_SEED
+                    // developer experiment: an upper bound for ANY culling / ordering improvement -- the ray starts with the
+                    // distance of its closest hit (from a first, ordinary pass over the same queue) as its limit
+                    if (sched.seed_t && hits[i].tri != 0xFFFFFFFFu) {
+                        const float lim = hits[i].t * (1.0f + 0x1p-20f);
+                        tr.hit.t = lim;
+                        s_best[lane_id] = ((unsigned long long)__float_as_uint(lim) << 32) | 0xFFFFFFFFull;
+                    }
+#endif
                 }
                 uint32_t n_idle = (uint32_t)__popcll(idle);
                 chunk_next += (n_idle < avail) ? n_idle : avail;
@@ -1501,6 +1511,15 @@ void launch_extend(hipStream_t s, const SceneDev &sc, const FrameDev &f, RayQueu
     uint32_t blocks = std::min((capacity + kExtendBlock - 1u) / kExtendBlock, max_waves);
     if (!blocks) return;
     unsigned long long *tt = reinterpret_cast<unsigned long long *>(trav_totals);
+    sched.seed_t = 0;
+#ifdef PTX_LAB_SEED
+    if (!any_hit && getenv("PTX_LAB_SEED")) {       // an ordinary pass first, then (below) the same queue again with seeded limits
+        if (tt) hipLaunchKernelGGL((k_extend<true, false>), dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, next, hits, tt, sched);
+        else hipLaunchKernelGGL((k_extend<false, false>), dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, next, hits, tt, sched);
+        (void)hipMemsetAsync(next, 0, kHeadsPerLaunch * sizeof(uint32_t), s);
+        sched.seed_t = 1;
+    }
+#endif
     if (any_hit) hipLaunchKernelGGL((k_extend<false, true>), dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, kLitShadowTmax, rays, count, next, hits, (unsigned long long *)nullptr, sched);
     else if (tt) hipLaunchKernelGGL((k_extend<true, false>), dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, next, hits, tt, sched);
     else hipLaunchKernelGGL((k_extend<false, false>), dim3(blocks), dim3(kExtendBlock), 0, s, sc, f.t_min, f.t_max, rays, count, next, hits, tt, sched);
