@@ -514,13 +514,16 @@ k_extend(SceneDev sc, float t_min, float t_max, RayQueue rays, const uint32_t *_
 }
 
 // ---------------------------------------------------------------- shade
-__device__ __forceinline__ f3 texel_at(const TexDesc &tx, const float *lut, uint32_t x, uint32_t y)
+__device__ __forceinline__ uint32_t texel_raw(const TexDesc &tx, uint32_t x, uint32_t y)
 {
     // texels are stored in tiles of 8 x 4 (one 128-byte line, see TexDesc): same texel, other address
     const uint32_t at = ((y >> 2) * tx.tiles_x + (x >> 3)) * 32u + ((y & 3u) << 3) + (x & 7u);
-    uint32_t texel = *reinterpret_cast<const uint32_t *>(tx.texels + (uint64_t)at * 4u);
+    return *reinterpret_cast<const uint32_t *>(tx.texels + (uint64_t)at * 4u);
+}
+__device__ __forceinline__ f3 texel_decode(uint32_t texel, uint32_t flags, const float *lut)
+{
     uint32_t r = texel & 0xFFu, g = (texel >> 8) & 0xFFu, b = (texel >> 16) & 0xFFu;
-    if (tx.srgb & 1u) return mk3(lut[r], lut[g], lut[b]);
+    if (flags & 1u) return mk3(lut[r], lut[g], lut[b]);
     return mk3((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f);
 }
 
@@ -549,19 +552,27 @@ __device__ __forceinline__ void linear_axis(float u, uint32_t size, bool repeat,
     i0 = (uint32_t)k0; i1 = (uint32_t)k1; a = fr;
 }
 
-__device__ __forceinline__ f3 sample_texture(const TexDesc &tx, const float *lut, float u, float v)
+// A texture fetch in two halves, so that a shading stage can put the loads of several fetches in flight together and
+// decode them where their values are needed (the lit integrator takes up to three taps per hit -- base colour,
+// metallic-roughness, normal -- whose texels are independent of each other but sat in three conditional blocks, i.e.
+// three serial round trips to a 100 MB working set).  tap_issue: addressing + the raw texel loads; tap_resolve: sRGB /
+// linear decode and the bilinear blend.  sample_texture = resolve(issue): one set of expression trees.
+struct TexTap {
+    uint32_t t00, t10, t01, t11;    // raw RGBA8 texels (nearest: t00 only)
+    float ax, ay;                   // bilinear weights
+    uint32_t flags;                 // the texture's flag word (bit0 sRGB, bit2 bilinear); 0xFFFFFFFF: no tap issued
+};
+__device__ __forceinline__ TexTap tap_issue(const TexDesc &tx, float u, float v)
 {
+    TexTap t; t.flags = tx.srgb; t.ax = 0.0f; t.ay = 0.0f; t.t10 = t.t01 = t.t11 = 0u;
     // vulkano SamplerCreateInfo::default(): nearest, clamp-to-edge, LOD 0 (graphics.rs:453-459)
     if (tx.srgb & 2u) { u = u - floorf(u); v = v - floorf(v); }   // build extension: wrap = repeat
     if (tx.srgb & 4u) {                                           // build extension: bilinear, blended after the sRGB decode
-        uint32_t x0, x1, y0, y1; float ax, ay;
-        linear_axis(u, tx.width, (tx.srgb & 2u) != 0u, x0, x1, ax);
-        linear_axis(v, tx.height, (tx.srgb & 2u) != 0u, y0, y1, ay);
-        f3 c00 = texel_at(tx, lut, x0, y0), c10 = texel_at(tx, lut, x1, y0), c01 = texel_at(tx, lut, x0, y1), c11 = texel_at(tx, lut, x1, y1);
-        float bx = 1.0f - ax, by = 1.0f - ay;
-        f3 top = c00 * bx + c10 * ax;
-        f3 bot = c01 * bx + c11 * ax;
-        return top * by + bot * ay;
+        uint32_t x0, x1, y0, y1;
+        linear_axis(u, tx.width, (tx.srgb & 2u) != 0u, x0, x1, t.ax);
+        linear_axis(v, tx.height, (tx.srgb & 2u) != 0u, y0, y1, t.ay);
+        t.t00 = texel_raw(tx, x0, y0); t.t10 = texel_raw(tx, x1, y0); t.t01 = texel_raw(tx, x0, y1); t.t11 = texel_raw(tx, x1, y1);
+        return t;
     }
     float fu = floorf(u * (float)tx.width), fv = floorf(v * (float)tx.height);
     float mu = (float)(tx.width - 1u), mv = (float)(tx.height - 1u);
@@ -569,7 +580,24 @@ __device__ __forceinline__ f3 sample_texture(const TexDesc &tx, const float *lut
     if (fu > mu) fu = mu;
     if (!(fv >= 0.0f)) fv = 0.0f;
     if (fv > mv) fv = mv;
-    return texel_at(tx, lut, (uint32_t)fu, (uint32_t)fv);
+    t.t00 = texel_raw(tx, (uint32_t)fu, (uint32_t)fv);
+    return t;
+}
+__device__ __forceinline__ f3 tap_resolve(const TexTap &t, const float *lut)
+{
+    if (t.flags & 4u) {
+        f3 c00 = texel_decode(t.t00, t.flags, lut), c10 = texel_decode(t.t10, t.flags, lut);
+        f3 c01 = texel_decode(t.t01, t.flags, lut), c11 = texel_decode(t.t11, t.flags, lut);
+        float bx = 1.0f - t.ax, by = 1.0f - t.ay;
+        f3 top = c00 * bx + c10 * t.ax;
+        f3 bot = c01 * bx + c11 * t.ax;
+        return top * by + bot * t.ay;
+    }
+    return texel_decode(t.t00, t.flags, lut);
+}
+__device__ __forceinline__ f3 sample_texture(const TexDesc &tx, const float *lut, float u, float v)
+{
+    return tap_resolve(tap_issue(tx, u, v), lut);
 }
 
 #ifdef PTX_SHADE_WAVES
@@ -948,16 +976,29 @@ __device__ __forceinline__ void lit_shade_hit(const SceneDev &sc, const FrameDev
     const LitMaterial lm = (lds_lm && lm_row < kLdsLitMaterials) ? lds_lm[lm_row] : sc.lit_materials[lm_row];
     f3 albedo = mk3(t2.w, s3.w, s4.x);
     const uint32_t tex = __float_as_uint(t0.w);
+    // the hit's texture taps -- base colour, normal, metallic-roughness -- go out together (one round trip, not three);
+    // each is decoded where the oracle's raygen_pixel_lit samples it.  The metallic-roughness tap is issued whatever lobe
+    // is chosen below (its value is only read on the opaque branch).
+    TexTap tap_b, tap_n, tap_m;
+    tap_b.flags = tap_n.flags = tap_m.flags = 0xFFFFFFFFu;
+    if (tex != 0xFFFFFFFFu) tap_b = tex < kLdsTextures ? tap_issue(s_tex[tex], tu, tv) : tap_issue(sc.textures[tex], tu, tv);
+    if (lm.normal_texture) {
+        const uint32_t nt = lm.normal_texture - 1u;
+        tap_n = nt < kLdsTextures ? tap_issue(s_tex[nt], tu, tv) : tap_issue(sc.textures[nt], tu, tv);
+    }
+    if (lm.mr_texture) {
+        const uint32_t mt = lm.mr_texture - 1u;
+        tap_m = mt < kLdsTextures ? tap_issue(s_tex[mt], tu, tv) : tap_issue(sc.textures[mt], tu, tv);
+    }
     if (tex != 0xFFFFFFFFu) {
-        f3 tx = tex < kLdsTextures ? sample_texture(s_tex[tex], s_lut, tu, tv) : sample_texture(sc.textures[tex], s_lut, tu, tv);
+        f3 tx = tap_resolve(tap_b, s_lut);
         albedo = tx * albedo;
     }
     if (lm.normal_texture) {
         // glTF normalTexture (oracle: raygen_pixel_lit): tangent-space normal, +Y up, the frame derived from the
         // triangle -- T along dP/du, B along -dP/dv, both made orthogonal to the shading normal; a degenerate uv
         // mapping or a perturbed normal below the geometric surface leaves the shading normal as it is
-        const uint32_t nt = lm.normal_texture - 1u;
-        const f3 tn = nt < kLdsTextures ? sample_texture(s_tex[nt], s_lut, tu, tv) : sample_texture(sc.textures[nt], s_lut, tu, tv);
+        const f3 tn = tap_resolve(tap_n, s_lut);
         const float mx = tn.x * 2.0f - 1.0f, my = tn.y * 2.0f - 1.0f, mz = tn.z * 2.0f - 1.0f;
         const f3 e1 = vb - va, e2 = vc - va;
         const float du1 = s2.w - s2.y, dv1 = s3.x - s2.z, du2 = s3.y - s2.y, dv2 = s3.z - s2.z;
@@ -1036,8 +1077,7 @@ __device__ __forceinline__ void lit_shade_hit(const SceneDev &sc, const FrameDev
     } else {
         float rough = t1.w, metal = lm.metallic;
         if (lm.mr_texture) {        // glTF: G = roughness, B = metallic, linear texels, multiplied into the factors
-            const uint32_t mt = lm.mr_texture - 1u;
-            const f3 mr = mt < kLdsTextures ? sample_texture(s_tex[mt], s_lut, tu, tv) : sample_texture(sc.textures[mt], s_lut, tu, tv);
+            const f3 mr = tap_resolve(tap_m, s_lut);
             rough = rough * mr.y;
             metal = metal * mr.z;
         }
@@ -1143,7 +1183,7 @@ __device__ __forceinline__ void lit_shade_hit(const SceneDev &sc, const FrameDev
 
 // `order` (optional): the queue positions grouped by the material class of their hit (k_material_sort): thread s of
 // the launch then shades ray order[s], so that a wave holds one kind of work -- sky, opaque lobes, glass.
-__global__ void __launch_bounds__(kShadeBlock) k_shade_lit(SceneDev sc, FrameDev f, ImagesDev img, uint32_t depth,
+__global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) k_shade_lit(SceneDev sc, FrameDev f, ImagesDev img, uint32_t depth,
                                                             RayQueue rays_in, const HitOut *__restrict__ hits,
                                                             uint32_t *__restrict__ counters, uint32_t capacity,
                                                             RayQueue rays_out, RayQueue shadow, float4 *__restrict__ results,
