@@ -239,9 +239,12 @@ def main():
     mine = [load_s, t_render * 1e3, (elapsed - t_render) * 1e3, float(sum(batches))]
     per_rank = [mine]
     if dist is not None:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, mine)
-        per_rank = gathered
+        # (plain tensors, like the other collectives of this script: nothing is pickled through the device)
+        dev = "cpu" if args.rehearse_gloo else "cuda:%d" % local_rank
+        m = torch.tensor(mine, dtype=torch.float64, device=dev)
+        parts = [torch.zeros_like(m) for _ in range(world)]
+        dist.all_gather(parts, m)
+        per_rank = [[float(v) for v in p.cpu()] for p in parts]
 
     if dist is not None:
         stat_dev = "cpu" if args.rehearse_gloo else "cuda:%d" % local_rank
