@@ -84,7 +84,7 @@ EXPORTS = [
 ]
 # ptx_option (include/ptx.h)
 (OPTION_FRAMES_IN_FLIGHT, OPTION_TAIL_RAYS, OPTION_TAIL_SHIFT, OPTION_TARGET_PATHS, OPTION_MATERIAL_SORT,
- OPTION_EXTEND_WAVES, OPTION_SHADE_GRID, OPTION_HOST_REFIT, OPTION_REFIT_VERIFY) = range(1, 10)
+ OPTION_EXTEND_WAVES, OPTION_SHADE_GRID, OPTION_HOST_REFIT, OPTION_REFIT_VERIFY, OPTION_TEXEL_SETS) = range(1, 11)
 
 _lib = None
 

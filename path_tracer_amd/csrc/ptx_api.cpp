@@ -124,6 +124,14 @@ struct ptx_context {
     LitMaterial *d_lit_materials = nullptr;       // lit integrator
     uint32_t n_dev_lit_materials = 0;             // rows in d_lit_materials (the material count at the last build)
     LightRec *d_lights = nullptr; float *d_light_cdf = nullptr; uint32_t n_lights = 0;
+    // texel sets of the lit integrator (ptx_kernels.h, LitMaterial): built on the first lit frame after a scene build,
+    // kept across builds (a texture never changes once added), keyed by the three texture slots (index + 1, 0 = none)
+    struct TexelSet { uint32_t base, normal, mr, flags, wh; uint32_t *d; uint64_t bytes; };
+    std::vector<TexelSet> texel_sets;
+    std::vector<LitMaterial> h_lit_materials;     // host copy of d_lit_materials (the set fields are filled in later)
+    bool texel_sets_on = true;                    // PTX_OPTION_TEXEL_SETS
+    bool texel_sets_stale = false;                // d_lit_materials does not carry the set fields the option asks for
+    uint64_t texel_set_bytes = 0;
     uint32_t built_options = 0;                   // scene options the current device scene was built with
     void *staging = nullptr; uint64_t staging_bytes = 0;   // pinned host staging for scene uploads
     // device refit (ptx_refit.hip): what the kernels need to re-flatten and refit without the host
@@ -440,6 +448,7 @@ int ptx_create_with_limits(int device_ordinal, const ptx_limits *limits, ptx_con
     if (const char *fi = getenv("PTX_FRAMES_IN_FLIGHT")) { long v = strtol(fi, nullptr, 10); if (v >= 1 && v <= kMaxSets) c->n_sets = (int)v; }
     c->host_refit_only = getenv("PTX_HOST_REFIT") != nullptr;
     c->refit_verify = getenv("PTX_REFIT_VERIFY") != nullptr;
+    if (const char *e = getenv("PTX_TEXEL_SETS")) c->texel_sets_on = atoi(e) != 0;
     CREATE_TRY(hipMalloc((void **)&c->d_totals, kNumTotals * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->d_totals, 0, kNumTotals * sizeof(uint64_t)));
     CREATE_TRY(hipMalloc((void **)&c->d_lut, 256 * sizeof(float)));
@@ -464,6 +473,7 @@ int ptx_destroy(ptx_context *c)
     for (TexDesc &t : c->textures) { void *p = (void *)t.texels; if (p) (void)hipFree(p); }
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_tri_of_rank); dfree(c->d_textures); dfree(c->d_lut);
     dfree(c->d_lit_materials); dfree(c->d_lights); dfree(c->d_light_cdf);
+    for (auto &ts : c->texel_sets) if (ts.d) (void)hipFree(ts.d);
     if (c->staging) (void)hipHostFree(c->staging);
     dfree(c->d_leaf_src); dfree(c->d_vertices); dfree(c->d_refit_inst); dfree(c->d_raw_box); dfree(c->d_node_box); dfree(c->d_refit_state);
     dfree(c->d_albedo); dfree(c->d_normal); dfree(c->d_depth); dfree(c->d_ids);
@@ -845,6 +855,7 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
         lm.transmission = c->material_ext[i].transmission; lm.ior = c->material_ext[i].ior;
         lm.mr_texture = c->material_ext[i].mr_texture;
         lm.normal_texture = c->material_ext[i].normal_texture; lm.emissive_texture = c->material_ext[i].emissive_texture;
+        lm._pad = c->materials[i].has_base_texture ? (uint64_t)c->materials[i].base_texture_indice + 1u : 0u;   // the base colour slot the ShadeRecs of this build carry (host-side note for ensure_texel_sets; no kernel reads it)
     }
 
     lap("lights");
@@ -926,6 +937,8 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
         HIP_TRY(c, hipMemcpy(c->d_lit_materials, lit_materials.data(), lit_materials.size() * sizeof(LitMaterial), hipMemcpyHostToDevice));
         c->n_dev_lit_materials = (uint32_t)lit_materials.size();
     }
+    c->h_lit_materials = lit_materials;          // without set fields: ensure_texel_sets fills them in on the first lit frame
+    c->texel_sets_stale = c->texel_sets_on;
     if (!lights.empty()) {
         HIP_TRY(c, hipMalloc((void **)&c->d_lights, lights.size() * sizeof(LightRec)));
         HIP_TRY(c, hipMemcpy(c->d_lights, lights.data(), lights.size() * sizeof(LightRec), hipMemcpyHostToDevice));
@@ -970,6 +983,67 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
     return PTX_OK;
 }
 
+
+// Texel sets of the lit integrator (ptx_kernels.h, LitMaterial).  Called by the first lit frame after a scene build (the
+// reference integrator never pays for them): every material whose base colour / normal / metallic-roughness textures --
+// those it has -- share one size and one wrap / filter mode, and which fetches more than one plain nearest texel, gets
+// its set (shared by materials with the same three textures, kept across builds), and the material rows go to the device
+// again with the set fields filled in.  A set that would not fit the budget is skipped: that material keeps the plain taps.
+static constexpr uint64_t kTexelSetBudget = 24ull << 30;      // bytes of texel sets per context
+static int ensure_texel_sets(ptx_context *c)
+{
+    if (!c->texel_sets_stale) return PTX_OK;
+    if (int r = sync_all(c)) return r;                        // frames in flight read the rows that are about to change
+    std::vector<LitMaterial> rows = c->h_lit_materials;
+    const size_t n = rows.size();
+    for (size_t i = 0; c->texel_sets_on && i < n; ++i) {
+        LitMaterial &lm = rows[i];
+        const uint32_t slot[3] = {(uint32_t)lm._pad, lm.normal_texture, lm.mr_texture};   // as of the build the device scene comes from
+        uint32_t present = 0, w = 0, h = 0, mode = 0;
+        bool ok = true;
+        for (int k = 0; k < 3 && ok; ++k) {
+            if (!slot[k]) continue;
+            if (slot[k] - 1u >= c->n_dev_textures) { ok = false; break; }     // not on the device (or not a texture): the plain path's business
+            const TexDesc &t = c->textures[slot[k] - 1u];
+            const uint32_t md = t.srgb & (uint32_t)(PTX_TEXTURE_REPEAT | PTX_TEXTURE_LINEAR);
+            if (!present) { w = t.width; h = t.height; mode = md; }
+            else if (t.width != w || t.height != h || md != mode) ok = false;
+            present |= 1u << k;
+        }
+        if (!ok || !present || w > 65533u || h > 65533u) continue;
+        const bool linear = (mode & PTX_TEXTURE_LINEAR) != 0;
+        if (!linear && present == 1u) continue;               // one nearest texel: nothing to gather
+        uint32_t flags = kTexelSetOn | ((mode & PTX_TEXTURE_REPEAT) ? kTexelSetRepeat : 0u) | (linear ? kTexelSetLinear : 0u);
+        if ((present & 6u) || !linear) flags |= kTexelSetHasB;
+        if ((present & 1u) && (c->textures[slot[0] - 1u].srgb & PTX_TEXTURE_SRGB)) flags |= kTexelSetBaseSrgb;
+        if ((present & 2u) && (c->textures[slot[1] - 1u].srgb & PTX_TEXTURE_SRGB)) flags |= kTexelSetNormalSrgb;
+        if ((present & 4u) && (c->textures[slot[2] - 1u].srgb & PTX_TEXTURE_SRGB)) flags |= kTexelSetMrSrgb;
+        const uint32_t wh = w | (h << 16);
+        const ptx_context::TexelSet *found = nullptr;
+        for (const auto &ts : c->texel_sets)
+            if (ts.base == slot[0] && ts.normal == slot[1] && ts.mr == slot[2] && ts.flags == flags && ts.wh == wh) { found = &ts; break; }
+        if (!found) {
+            const uint64_t bytes = texel_set_bytes(w, h, flags);
+            if (c->texel_set_bytes + bytes > kTexelSetBudget) continue;
+            ptx_context::TexelSet ts{slot[0], slot[1], slot[2], flags, wh, nullptr, bytes};
+            hipError_t e = hipMalloc((void **)&ts.d, bytes);
+            if (e != hipSuccess) { (void)hipGetLastError(); continue; }   // no memory for it: the plain taps stay
+            const TexDesc none{};
+            launch_build_texel_set(c->stream, ts.d, (present & 1u) ? c->textures[slot[0] - 1u] : none, (present & 2u) ? c->textures[slot[1] - 1u] : none,
+                                   (present & 4u) ? c->textures[slot[2] - 1u] : none, present, w, h, flags);
+            c->texel_set_bytes += bytes;
+            c->texel_sets.push_back(ts);
+            found = &c->texel_sets.back();
+        }
+        lm.set_flags = found->flags; lm.set_wh = found->wh; lm.set_texels = found->d;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!rows.empty() && c->d_lit_materials && rows.size() == c->n_dev_lit_materials)
+        HIP_TRY(c, hipMemcpy(c->d_lit_materials, rows.data(), rows.size() * sizeof(LitMaterial), hipMemcpyHostToDevice));
+    c->texel_sets_stale = false;
+    return PTX_OK;
+}
+
 extern "C" {
 
 int ptx_resize(ptx_context *c, uint32_t w, uint32_t h)
@@ -1010,6 +1084,7 @@ int ptx_render_batch(ptx_context *c, const ptx_uniforms *u, const ptx_camera *ca
     const bool lit = p.integrator == PTX_INTEGRATOR_LIT;
     if (n_samples == 0) return PTX_OK;
     if (int r = bind(c)) return r;
+    if (lit) if (int r = ensure_texel_sets(c)) return r;
 
     const uint64_t npix = (uint64_t)c->width * c->height;
     uint64_t chunk = std::max<uint64_t>(1, c->target_paths / npix);
@@ -1310,6 +1385,10 @@ int ptx_set_option(ptx_context *c, int key, uint64_t value)
         return PTX_OK;
     case PTX_OPTION_HOST_REFIT: c->host_refit_only = value != 0; return PTX_OK;
     case PTX_OPTION_REFIT_VERIFY: c->refit_verify = value != 0; return PTX_OK;
+    case PTX_OPTION_TEXEL_SETS:
+        if (value > 1) return fail(c, PTX_ERR_INVALID, "ptx_set_option: texel sets are 0 or 1");
+        if (c->texel_sets_on != (value != 0)) { c->texel_sets_on = value != 0; c->texel_sets_stale = true; }   // the next lit frame re-writes the material rows
+        return PTX_OK;
     default: return fail(c, PTX_ERR_INVALID, "ptx_set_option: unknown option key");
     }
 }
@@ -1328,6 +1407,7 @@ int ptx_get_option(ptx_context *c, int key, uint64_t *value)
     case PTX_OPTION_SHADE_GRID: *value = c->shade_grid ? c->shade_grid : default_shade_grid(); return PTX_OK;
     case PTX_OPTION_HOST_REFIT: *value = c->host_refit_only ? 1 : 0; return PTX_OK;
     case PTX_OPTION_REFIT_VERIFY: *value = c->refit_verify ? 1 : 0; return PTX_OK;
+    case PTX_OPTION_TEXEL_SETS: *value = c->texel_sets_on ? 1 : 0; return PTX_OK;
     default: return fail(c, PTX_ERR_INVALID, "ptx_get_option: unknown option key");
     }
 }

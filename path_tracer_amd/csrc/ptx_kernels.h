@@ -59,9 +59,28 @@ struct alignas(16) LitMaterial {
     float pdf_area;      // light pick density per area for a point on a triangle of this material (luminance / total power)
     uint32_t mr_texture; // metallic-roughness texture index + 1, 0 = none
     uint32_t normal_texture, emissive_texture;   // index + 1, 0 = none (ptx_material_ext)
-    uint32_t _pad[2];
+    // The material's TEXEL SET (0 flags: none, the taps go to the three textures one by one): base colour, normal and
+    // metallic-roughness texels of one texel position side by side, see kTexelSet* below.
+    uint32_t set_flags;
+    uint32_t set_wh;     // width | height << 16 of the set's textures
+    const uint32_t *set_texels;
+    uint64_t _pad;
 };
-static_assert(sizeof(LitMaterial) == 48, "LitMaterial must be 48 bytes");
+static_assert(sizeof(LitMaterial) == 64, "LitMaterial must be 64 bytes");
+// Texel sets (lit integrator, built by ptx_api.cpp: ensure_texel_sets).  A hit of the lit integrator reads up to three
+// textures at ONE uv -- 12 scattered one-dword loads with bilinear filtering, and the stage's time follows the number of
+// such requests, not their bytes (nearest instead of bilinear, 3 loads instead of 12, takes 8.3
+// instead of 11.0 ms per step).  When the textures of a material have one size and one wrap / filter mode, the build
+// interleaves them into one array with one ENTRY per fetch position, holding everything that fetch reads:
+//   word A = base colour r, g, b + metallic-roughness g in the top byte; word B = normal r, g, b + metallic-roughness b
+//   (no decode reads a texel's alpha; the metallic-roughness texel is put together again from the two top bytes);
+//   nearest:  entry (x, y) = A, B of texel (x, y): 8 bytes, row-major;
+//   bilinear: entry (k0x + 1, k0y + 1) for the lower texel indices k0 in [-1, size] that linear_axis_k0 can return =
+//             A00 A10 A01 A11 [B00 B10 B01 B11] of the 2 x 2 footprint with wrap / clamp already applied by the same
+//             axis_pair the plain path uses: 16 or 32 bytes, rows of width + 2 entries.  One or two 16-byte loads.
+// Same texels, same arithmetic after the loads: the image keeps its bits.
+constexpr uint32_t kTexelSetOn = 1u, kTexelSetRepeat = 2u, kTexelSetLinear = 4u, kTexelSetHasB = 8u;
+constexpr uint32_t kTexelSetBaseSrgb = 1u << 8, kTexelSetNormalSrgb = 1u << 9, kTexelSetMrSrgb = 1u << 10;
 struct alignas(16) LightRec {          // one emissive triangle, world space
     float a[3]; float pdf_area;        // pick probability / area
     float b[3]; float le_r;
@@ -170,6 +189,10 @@ void launch_shade_lit(hipStream_t s, const SceneDev &sc, const FrameDev &f, cons
 void launch_material_sort(hipStream_t s, const SceneDev &sc, const HitOut *hits, const uint32_t *count, uint32_t capacity,
                           uint32_t *class_count, uint32_t *order, uint32_t grid_cap = 0);
 // adds the contribution of every unoccluded occlusion ray of bounce `depth` to its path's radiance
+// texel sets of the lit integrator (LitMaterial): bytes of one set, and its build from the (tiled) textures
+uint64_t texel_set_bytes(uint32_t w, uint32_t h, uint32_t set_flags);
+void launch_build_texel_set(hipStream_t s, uint32_t *dst, const TexDesc &tb, const TexDesc &tn, const TexDesc &tm, uint32_t present,
+                            uint32_t w, uint32_t h, uint32_t set_flags);
 void launch_shadow_resolve(hipStream_t s, uint32_t depth, RayQueue shadow, const HitOut *hits, const uint32_t *counters,
                            uint32_t capacity, float4 *results, uint32_t grid_cap = 0);
 uint32_t default_shade_grid();      // PTX_SHADE_GRID or 8192

@@ -29,6 +29,10 @@ constexpr int kExtendBlock = 64;    // one wave per workgroup: resources free as
 #define PTX_SHADE_BLOCK 512
 #endif
 constexpr int kShadeBlock = PTX_SHADE_BLOCK;   // one queue-tail atomic per block (a single word takes only ~88 M atomics/s); 512 threads x 89 VGPRs = 5 waves/SIMD
+#ifndef PTX_LIT_BLOCK
+#define PTX_LIT_BLOCK 256
+#endif
+constexpr int kLitBlock = PTX_LIT_BLOCK;       // k_shade_lit: a tile lasts as long as its slowest wave (divergent material code), so smaller blocks wait less: 256 threads 7.6 ms of shading per step, 512 threads 8.1, 128 threads 11.0 -- two queue-tail atomics per block and tile
 
 __device__ __forceinline__ f3 mat4_mul(const float *m, float x, float y, float z, float w)
 {
@@ -527,8 +531,10 @@ __device__ __forceinline__ f3 texel_decode(uint32_t texel, uint32_t flags, const
     return mk3((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f);
 }
 
-// PTX_TEXTURE_LINEAR: texel centres at i + 0.5; the pair of texels and the blend weight along one axis
-__device__ __forceinline__ void linear_axis(float u, uint32_t size, bool repeat, uint32_t &i0, uint32_t &i1, float &a)
+// PTX_TEXTURE_LINEAR: texel centres at i + 0.5.  linear_axis_k0: the lower texel index of the pair, in [-1, size], and
+// the blend weight; axis_pair: the two texel indices with wrap / clamp applied.  (Two functions because the texel sets
+// of the lit integrator tabulate axis_pair for every k0: their builder and the plain fetch share this code.)
+__device__ __forceinline__ int32_t linear_axis_k0(float u, uint32_t size, float &a)
 {
     float x = u * (float)size - 0.5f;
     float xf = floorf(x);
@@ -538,7 +544,12 @@ __device__ __forceinline__ void linear_axis(float u, uint32_t size, bool repeat,
     float hi = (float)size;
     if (!(xf >= -1.0f)) xf = -1.0f;
     if (xf > hi) xf = hi;
-    int32_t k0 = (int32_t)xf, k1 = k0 + 1, n = (int32_t)size;
+    a = fr;
+    return (int32_t)xf;
+}
+__device__ __forceinline__ void axis_pair(int32_t k0, uint32_t size, bool repeat, uint32_t &i0, uint32_t &i1)
+{
+    int32_t k1 = k0 + 1, n = (int32_t)size;
     if (repeat) {
         if (k0 < 0) k0 += n;
         if (k0 >= n) k0 -= n;
@@ -549,7 +560,11 @@ __device__ __forceinline__ void linear_axis(float u, uint32_t size, bool repeat,
         if (k0 > n - 1) k0 = n - 1;
         if (k1 > n - 1) k1 = n - 1;
     }
-    i0 = (uint32_t)k0; i1 = (uint32_t)k1; a = fr;
+    i0 = (uint32_t)k0; i1 = (uint32_t)k1;
+}
+__device__ __forceinline__ void linear_axis(float u, uint32_t size, bool repeat, uint32_t &i0, uint32_t &i1, float &a)
+{
+    axis_pair(linear_axis_k0(u, size, a), size, repeat, i0, i1);
 }
 
 // A texture fetch in two halves, so that a shading stage can put the loads of several fetches in flight together and
@@ -934,11 +949,46 @@ __device__ __forceinline__ uint32_t block_reserve(bool flag, const BlockScan &bs
     return slot;
 }
 
+// Both reservations of a k_shade_lit tile in ONE pass: the per-wave counts of the two flags travel packed in one word
+// (<= 64 each), one lane issues both queue-tail atomics back to back, and the LDS words alternate between two buffers
+// from tile to tile (`buf`), so that no barrier is needed behind the reads: two barriers per tile instead of six.  (A
+// wave can only write buffer b again two tiles later, behind the two barriers of the tile in between, which every wave
+// reaches after its reads of b.)  `wave_cnt`: 2 x kLitBlock / 64 words, `base`: 2 x 2 words.
+__device__ __forceinline__ void block_reserve2(bool flag_a, bool flag_b, uint32_t *wave_cnt, uint32_t *base, uint32_t buf,
+                                               uint32_t *counter_a, uint32_t *counter_b, uint32_t &slot_a, uint32_t &slot_b)
+{
+    constexpr uint32_t kWaves = kLitBlock / 64;
+    const unsigned long long ma = __ballot(flag_a), mb = __ballot(flag_b);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *cnt = wave_cnt + buf * kWaves, *bs = base + buf * 2u;
+    if (lane == 0) cnt[wave] = (uint32_t)__popcll(ma) | ((uint32_t)__popcll(mb) << 16);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        uint32_t c = lane < kWaves ? cnt[lane] : 0u;
+#pragma unroll
+        for (int d = 1; d < (int)kWaves; d <<= 1) {
+            uint32_t t = __shfl_up(c, d, 64);
+            if ((int)lane >= d) c += t;               // the halves cannot carry into each other: at most kLitBlock each
+        }
+        if (lane < kWaves) cnt[lane] = c;
+        if (lane == kWaves - 1) {
+            const uint32_t na = c & 0xFFFFu, nb = c >> 16;
+            const uint32_t ba = na ? atomicAdd(counter_a, na) : 0u;
+            const uint32_t bb = nb ? atomicAdd(counter_b, nb) : 0u;
+            bs[0] = ba; bs[1] = bb;
+        }
+    }
+    __syncthreads();
+    const uint32_t before = wave ? cnt[wave - 1] : 0u;
+    slot_a = bs[0] + (before & 0xFFFFu) + __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
+    slot_b = bs[1] + (before >> 16) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
+}
+
 // One hit of the lit integrator (oracle: raygen_pixel_lit, the `hit` branch): emission, one next-event-estimation sample
 // (its occlusion ray comes back in q0 .. q2), BSDF sampling, Russian roulette.  Shared by the wavefront stage (k_shade_lit)
 // and the fused tail (k_tail_lit): one set of expression trees, so both give the oracle's bits.
 constexpr uint32_t kLdsCdf = 4096;          // entries of k_shade_lit's LDS light table (16 KB)
-constexpr uint32_t kLdsLitMaterials = 128;  // rows of SceneDev::lit_materials k_shade_lit keeps in LDS (6 KB): the row index comes out of the
+constexpr uint32_t kLdsLitMaterials = 128;  // rows of SceneDev::lit_materials k_shade_lit keeps in LDS (8 KB): the row index comes out of the
                                             // triangle's record, so a global fetch of it is one more dependent round trip per hit
 struct LitState {
     f3 thr, add, gb_normal, new_o, new_d;
@@ -981,6 +1031,48 @@ __device__ __forceinline__ void lit_shade_hit(const SceneDev &sc, const FrameDev
     // is chosen below (its value is only read on the opaque branch).
     TexTap tap_b, tap_n, tap_m;
     tap_b.flags = tap_n.flags = tap_m.flags = 0xFFFFFFFFu;
+    if (lm.set_flags) {
+        // the material's texel set (ptx_kernels.h): everything the three fetches read sits in one entry -- one or two
+        // 16-byte loads instead of up to twelve scattered dwords; the taps are then filled with the same raw texels
+        const uint32_t sf = lm.set_flags, sw = lm.set_wh & 0xFFFFu, sh = lm.set_wh >> 16;
+        float u = tu, v = tv;
+        if (sf & kTexelSetRepeat) { u = u - floorf(u); v = v - floorf(v); }
+        uint32_t a00 = 0, a10 = 0, a01 = 0, a11 = 0, b00 = 0, b10 = 0, b01 = 0, b11 = 0;
+        float ax = 0.0f, ay = 0.0f;
+        if (sf & kTexelSetLinear) {
+            const int32_t kx = linear_axis_k0(u, sw, ax), ky = linear_axis_k0(v, sh, ay);
+            const uint32_t entry = (uint32_t)(ky + 1) * (sw + 2u) + (uint32_t)(kx + 1);
+            const uint4 *e = reinterpret_cast<const uint4 *>(lm.set_texels) + (uint64_t)entry * ((sf & kTexelSetHasB) ? 2u : 1u);
+            const uint4 qa = e[0];
+            a00 = qa.x; a10 = qa.y; a01 = qa.z; a11 = qa.w;
+            if (sf & kTexelSetHasB) { const uint4 qb = e[1]; b00 = qb.x; b10 = qb.y; b01 = qb.z; b11 = qb.w; }
+        } else {
+            float fu = floorf(u * (float)sw), fv = floorf(v * (float)sh);
+            const float mu = (float)(sw - 1u), mv = (float)(sh - 1u);
+            if (!(fu >= 0.0f)) fu = 0.0f;
+            if (fu > mu) fu = mu;
+            if (!(fv >= 0.0f)) fv = 0.0f;
+            if (fv > mv) fv = mv;
+            const uint2 q = reinterpret_cast<const uint2 *>(lm.set_texels)[(uint64_t)((uint32_t)fv * sw + (uint32_t)fu)];
+            a00 = q.x; b00 = q.y;
+        }
+        const uint32_t shared = sf & (kTexelSetRepeat | kTexelSetLinear);
+        if (tex != 0xFFFFFFFFu) {
+            tap_b.t00 = a00; tap_b.t10 = a10; tap_b.t01 = a01; tap_b.t11 = a11; tap_b.ax = ax; tap_b.ay = ay;
+            tap_b.flags = shared | ((sf & kTexelSetBaseSrgb) ? 1u : 0u);
+        }
+        if (lm.normal_texture) {
+            tap_n.t00 = b00; tap_n.t10 = b10; tap_n.t01 = b01; tap_n.t11 = b11; tap_n.ax = ax; tap_n.ay = ay;
+            tap_n.flags = shared | ((sf & kTexelSetNormalSrgb) ? 1u : 0u);
+        }
+        if (lm.mr_texture) {
+            // g from word A's top byte, b from word B's (the decode reads bytes 1 and 2)
+            tap_m.t00 = ((a00 >> 24) << 8) | ((b00 >> 24) << 16); tap_m.t10 = ((a10 >> 24) << 8) | ((b10 >> 24) << 16);
+            tap_m.t01 = ((a01 >> 24) << 8) | ((b01 >> 24) << 16); tap_m.t11 = ((a11 >> 24) << 8) | ((b11 >> 24) << 16);
+            tap_m.ax = ax; tap_m.ay = ay;
+            tap_m.flags = shared | ((sf & kTexelSetMrSrgb) ? 1u : 0u);
+        }
+    } else {
     if (tex != 0xFFFFFFFFu) tap_b = tex < kLdsTextures ? tap_issue(s_tex[tex], tu, tv) : tap_issue(sc.textures[tex], tu, tv);
     if (lm.normal_texture) {
         const uint32_t nt = lm.normal_texture - 1u;
@@ -989,6 +1081,7 @@ __device__ __forceinline__ void lit_shade_hit(const SceneDev &sc, const FrameDev
     if (lm.mr_texture) {
         const uint32_t mt = lm.mr_texture - 1u;
         tap_m = mt < kLdsTextures ? tap_issue(s_tex[mt], tu, tv) : tap_issue(sc.textures[mt], tu, tv);
+    }
     }
     if (tex != 0xFFFFFFFFu) {
         f3 tx = tap_resolve(tap_b, s_lut);
@@ -1183,7 +1276,7 @@ __device__ __forceinline__ void lit_shade_hit(const SceneDev &sc, const FrameDev
 
 // `order` (optional): the queue positions grouped by the material class of their hit (k_material_sort): thread s of
 // the launch then shades ray order[s], so that a wave holds one kind of work -- sky, opaque lobes, glass.
-__global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) k_shade_lit(SceneDev sc, FrameDev f, ImagesDev img, uint32_t depth,
+__global__ void __launch_bounds__(kLitBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) k_shade_lit(SceneDev sc, FrameDev f, ImagesDev img, uint32_t depth,
                                                             RayQueue rays_in, const HitOut *__restrict__ hits,
                                                             uint32_t *__restrict__ counters, uint32_t capacity,
                                                             RayQueue rays_out, RayQueue shadow, float4 *__restrict__ results,
@@ -1191,27 +1284,27 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
 {
     __shared__ float s_lut[256];
     __shared__ TexDesc s_tex[kLdsTextures];
-    __shared__ uint32_t s_cnt[kShadeBlock / 64];
-    __shared__ uint32_t s_base, s_hits;
+    __shared__ uint32_t s_cnt[2 * (kLitBlock / 64)];
+    __shared__ uint32_t s_base[4], s_hits;
     __shared__ float s_cdf[kLdsCdf];        // light pick: last CDF value of every cdf_stride lights (see lit_shade_hit)
     __shared__ LitMaterial s_lm[kLdsLitMaterials];
 
-    // capped grid, tiles of kShadeBlock rays (see k_shade)
+    // capped grid, tiles of kLitBlock rays (see k_shade)
     const uint32_t n_live = counters[depth];
-    if ((uint64_t)blockIdx.x * kShadeBlock >= n_live) return;
+    if ((uint64_t)blockIdx.x * kLitBlock >= n_live) return;
     if (threadIdx.x == 0) s_hits = 0;
     const uint32_t cdf_stride = (sc.n_lights + kLdsCdf - 1u) / kLdsCdf > 0u ? (sc.n_lights + kLdsCdf - 1u) / kLdsCdf : 1u;
-    for (uint32_t j = threadIdx.x; j * cdf_stride < sc.n_lights; j += kShadeBlock) {
+    for (uint32_t j = threadIdx.x; j * cdf_stride < sc.n_lights; j += kLitBlock) {
         const uint32_t last = (j + 1u) * cdf_stride - 1u;
         s_cdf[j] = sc.light_cdf[last < sc.n_lights ? last : sc.n_lights - 1u];
     }
-    if (threadIdx.x < 256) s_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];
+    for (uint32_t j = threadIdx.x; j < 256u; j += kLitBlock) s_lut[j] = sc.srgb_lut[j];
     {
         const uint32_t nw = (sc.n_textures < kLdsTextures ? sc.n_textures : kLdsTextures) * (uint32_t)(sizeof(TexDesc) / 4);
-        for (uint32_t w = threadIdx.x; w < nw; w += kShadeBlock)
+        for (uint32_t w = threadIdx.x; w < nw; w += kLitBlock)
             reinterpret_cast<uint32_t *>(s_tex)[w] = reinterpret_cast<const uint32_t *>(sc.textures)[w];
         const uint32_t nm = (sc.n_lit_materials < kLdsLitMaterials ? sc.n_lit_materials : kLdsLitMaterials) * (uint32_t)(sizeof(LitMaterial) / 4);
-        for (uint32_t w = threadIdx.x; w < nm; w += kShadeBlock)
+        for (uint32_t w = threadIdx.x; w < nm; w += kLitBlock)
             reinterpret_cast<uint32_t *>(s_lm)[w] = reinterpret_cast<const uint32_t *>(sc.lit_materials)[w];
     }
     // The next tile's ray + hit are fetched behind this tile's shading, in front of its two queue reservations (two atomic
@@ -1219,9 +1312,9 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
     // held across the shading itself (124 VGPRs keep two blocks per CU).
     const float4 kZero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     auto fetch_ray = [&](uint32_t tile_, float4 &a0, float4 &a1, float4 &a2, float2 &h) {
-        const uint32_t slot_ = tile_ * kShadeBlock + threadIdx.x;
+        const uint32_t slot_ = tile_ * kLitBlock + threadIdx.x;
         a0 = kZero4; a1 = kZero4; a2 = kZero4; h = make_float2(0.0f, __uint_as_float(0xFFFFFFFFu));
-        if ((uint64_t)tile_ * kShadeBlock >= n_live) return;
+        if ((uint64_t)tile_ * kLitBlock >= n_live) return;
         const bool valid_ = slot_ < capacity && slot_ < n_live;
         const uint32_t i_ = (order && valid_) ? order[slot_] : slot_;
         if (i_ < capacity) {
@@ -1234,8 +1327,10 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
     };
     float4 r0, r1, r2; float2 hr;
     fetch_ray(blockIdx.x, r0, r1, r2, hr);
-    for (uint32_t tile = blockIdx.x; (uint64_t)tile * kShadeBlock < n_live; tile += gridDim.x) {
-    const uint32_t slot_in = tile * kShadeBlock + threadIdx.x;
+    __syncthreads();      // the LDS tables are complete; the tile loop's only barriers are the two of block_reserve2
+    uint32_t buf = 0;
+    for (uint32_t tile = blockIdx.x; (uint64_t)tile * kLitBlock < n_live; tile += gridDim.x, buf ^= 1u) {
+    const uint32_t slot_in = tile * kLitBlock + threadIdx.x;
     const bool valid = slot_in < capacity && slot_in < n_live;
     const uint32_t tri = valid ? __float_as_uint(hr.y) : 0xFFFFFFFFu;
     float4 t0 = kZero4, t1 = kZero4, t2 = kZero4, s0 = kZero4, s1 = kZero4, s2 = kZero4, s3 = kZero4, s4 = kZero4;
@@ -1243,7 +1338,6 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
         const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri);
         t0 = sp[0]; t1 = sp[1]; t2 = sp[2]; s0 = sp[3]; s1 = sp[4]; s2 = sp[5]; s3 = sp[6]; s4 = sp[7];
     }
-    __syncthreads();
 
     bool alive = false, was_hit = false, want_shadow = false;
     float4 o0, o1, o2, q0, q1, q2;
@@ -1296,18 +1390,18 @@ __global__ void __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_e
     }
 
     fetch_ray(tile + gridDim.x, r0, r1, r2, hr);      // this tile's ray registers are dead: everything it produced is in o0 .. q2
-    BlockScan bs; bs.wave_cnt = s_cnt; bs.base = &s_base;
     {
         // hits of the block: LDS atomic per wave, one global atomic per block (a single word takes ~88 M atomics/s)
         unsigned long long hitm = __ballot(was_hit);
         if ((threadIdx.x & 63u) == 0 && hitm) atomicAdd(&s_hits, (uint32_t)__popcll(hitm));
     }
-    const uint32_t slot = block_reserve(alive, bs, &counters[depth + 1u]);
+    uint32_t slot, sslot;
+    block_reserve2(alive, want_shadow, s_cnt, s_base, buf, &counters[depth + 1u], &counters[kShadowCount + depth], slot, sslot);
     if (alive) { rays_out.org[slot] = o0; rays_out.dir[slot] = o1; rays_out.thr[slot] = o2; }
-    const uint32_t sslot = block_reserve(want_shadow, bs, &counters[kShadowCount + depth]);
     if (want_shadow) { shadow.org[sslot] = q0; shadow.dir[sslot] = q1; shadow.thr[sslot] = q2; }
     }
-    if (threadIdx.x == 0 && s_hits) atomicAdd(&counters[kHitCounter], s_hits);      // block_reserve's barriers order the LDS adds before this read
+    __syncthreads();      // every wave's LDS add of its hits is done
+    if (threadIdx.x == 0 && s_hits) atomicAdd(&counters[kHitCounter], s_hits);
 }
 
 // Fused tail of the lit integrator: k_tail's idea for PTX_INTEGRATOR_LIT.  From the first bounce whose expected queue is
@@ -1613,10 +1707,10 @@ void launch_shade_lit(hipStream_t s, const SceneDev &sc, const FrameDev &f, cons
                       RayQueue rays_in, const HitOut *hits, uint32_t *counters, uint32_t capacity, RayQueue rays_out,
                       RayQueue shadow, float4 *results, const uint32_t *order, uint32_t grid_cap)
 {
-    uint32_t blocks = (capacity + kShadeBlock - 1u) / kShadeBlock;
+    uint32_t blocks = (capacity + kLitBlock - 1u) / kLitBlock;
     if (!blocks) return;
     blocks = std::min(blocks, shade_grid_cap(grid_cap));
-    hipLaunchKernelGGL(k_shade_lit, dim3(blocks), dim3(kShadeBlock), 0, s, sc, f, img, depth, rays_in, hits, counters,
+    hipLaunchKernelGGL(k_shade_lit, dim3(blocks), dim3(kLitBlock), 0, s, sc, f, img, depth, rays_in, hits, counters,
                        capacity, rays_out, shadow, results, order);
 }
 
@@ -1638,6 +1732,58 @@ void launch_shadow_resolve(hipStream_t s, uint32_t depth, RayQueue shadow, const
     if (!blocks) return;
     blocks = std::min(blocks, shade_grid_cap(grid_cap) * 2u);
     hipLaunchKernelGGL(k_shadow_resolve, dim3(blocks), dim3(256), 0, s, depth, shadow, hits, counters, results);
+}
+
+// Texel sets (ptx_kernels.h): one thread per entry gathers what the three fetches of that position read.  `present`:
+// bit0 base, bit1 normal, bit2 metallic-roughness; the descriptors of absent planes are not read.
+__global__ void __launch_bounds__(256) k_build_texel_set(uint32_t *__restrict__ dst, TexDesc tb, TexDesc tn, TexDesc tm, uint32_t present,
+                                                          uint32_t w, uint32_t h, uint32_t set_flags)
+{
+    const bool linear = (set_flags & kTexelSetLinear) != 0u, has_b = (set_flags & kTexelSetHasB) != 0u;
+    const uint32_t ew = linear ? w + 2u : w, eh = linear ? h + 2u : h;
+    const uint64_t n = (uint64_t)ew * eh;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t ex = (uint32_t)(i % ew), ey = (uint32_t)(i / ew);
+        uint32_t xs[2], ys[2];
+        if (linear) {
+            axis_pair((int32_t)ex - 1, w, (set_flags & kTexelSetRepeat) != 0u, xs[0], xs[1]);
+            axis_pair((int32_t)ey - 1, h, (set_flags & kTexelSetRepeat) != 0u, ys[0], ys[1]);
+        } else {
+            xs[0] = xs[1] = ex; ys[0] = ys[1] = ey;
+        }
+        uint32_t wa[4], wb[4];
+        const int np = linear ? 4 : 1;
+        for (int k = 0; k < np; ++k) {
+            const uint32_t x = xs[k & 1], y = ys[k >> 1];
+            const uint32_t b = (present & 1u) ? texel_raw(tb, x, y) : 0u;
+            const uint32_t nr = (present & 2u) ? texel_raw(tn, x, y) : 0u;
+            const uint32_t m = (present & 4u) ? texel_raw(tm, x, y) : 0u;
+            wa[k] = (b & 0x00FFFFFFu) | (((m >> 8) & 0xFFu) << 24);
+            wb[k] = (nr & 0x00FFFFFFu) | (((m >> 16) & 0xFFu) << 24);
+        }
+        if (linear) {
+            uint32_t *e = dst + i * (has_b ? 8u : 4u);
+            for (int k = 0; k < 4; ++k) e[k] = wa[k];
+            if (has_b) for (int k = 0; k < 4; ++k) e[4 + k] = wb[k];
+        } else {
+            dst[i * 2u] = wa[0]; dst[i * 2u + 1u] = wb[0];
+        }
+    }
+}
+
+uint64_t texel_set_bytes(uint32_t w, uint32_t h, uint32_t set_flags)
+{
+    if (set_flags & kTexelSetLinear) return (uint64_t)(w + 2u) * (h + 2u) * ((set_flags & kTexelSetHasB) ? 32u : 16u);
+    return (uint64_t)w * h * 8u;
+}
+
+void launch_build_texel_set(hipStream_t s, uint32_t *dst, const TexDesc &tb, const TexDesc &tn, const TexDesc &tm, uint32_t present,
+                            uint32_t w, uint32_t h, uint32_t set_flags)
+{
+    const uint64_t n = (set_flags & kTexelSetLinear) ? (uint64_t)(w + 2u) * (h + 2u) : (uint64_t)w * h;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255u) / 256u, 65536u);
+    if (!blocks) return;
+    hipLaunchKernelGGL(k_build_texel_set, dim3(blocks), dim3(256), 0, s, dst, tb, tn, tm, present, w, h, set_flags);
 }
 
 void launch_resolve(hipStream_t s, const FrameDev &f, const ImagesDev &img, const float4 *results, uint32_t n_samples)

@@ -155,6 +155,61 @@ def test_lit_stress_scene_many_lights(oracle, gpu_ctx_factory):
     assert ctx.stats()["lights"] == len(sc.lights())
 
 
+def test_texel_sets_every_mode_against_oracle_and_plain_taps(oracle, gpu_ctx_factory):
+    """Texel sets (PTX_OPTION_TEXEL_SETS, include/ptx.h): the materials of the stress scene get normal and metallic-roughness
+    maps of their base texture's odd little size (4..6 x 3..7 texels, uv far outside [0, 1]: every edge entry of a set is
+    read) in all four wrap / filter combinations -- all three planes, base + normal, normal + metallic-roughness without a
+    base texture, base alone (bilinear: a one-load set; nearest: no set), sRGB and linear base texels -- and every fifth a
+    metallic-roughness map of ANOTHER size (no set: the plain taps).  Sets on (default) == oracle == sets off, bit for bit,
+    with the same ray, hit and occlusion-ray counts; toggling the option on a live context takes effect on the next frame."""
+    from path_tracer_amd import capi
+    ing = stress_scene(n_textures=40, n_confetti=6000)
+    rng = np.random.default_rng(23)
+    n_mat = len(ing.materials)
+    modes = [(2 if t % 2 else 0) | (4 if t % 3 else 0) for t in range(n_mat)]
+    ing.textures = [(rgba, flags | modes[t]) for t, (rgba, flags) in enumerate(ing.textures)]
+    for t in range(n_mat):
+        h, w = ing.textures[t][0].shape[:2]
+        ing.materials[t]["metallic"] = np.float32([0.0, 1.0, 0.5, 0.3][t % 4])
+        if t % 9 == 0:
+            ing.material_ext[t]["emissive"] = rng.uniform(0.5, 4.0, 3).astype(np.float32)
+        if t % 7 == 6:
+            continue                                            # base texture alone
+        if t % 3 != 1:
+            ing.textures.append((rng.integers(0, 256, (h, w, 4), dtype=np.uint8), modes[t]))
+            ing.material_ext[t]["normal_texture"] = len(ing.textures)
+        if t % 4 != 2:
+            shape = (h + 1, w, 4) if t % 5 == 4 else (h, w, 4)   # every fifth: another size, no set
+            ing.textures.append((rng.integers(0, 256, shape, dtype=np.uint8), modes[t]))
+            ing.material_ext[t]["mr_texture"] = len(ing.textures)
+    opts = capi.SCENE_WORLD_NORMALS | capi.SCENE_TEXTURE_TIMES_FACTOR
+    sc = oracle.scene_from_ingest(ing, options=opts, with_material_ext=True)
+    cam = oracle.camera_matrices([0.0, 0.2, 4.5], oracle.yaw_quat(0), np.deg2rad(np.float32(60)), 1.0, 0.1, 1000.0)
+    want = sc.render(cam, 144, 144, 2, SEED, params=oracle.default_params(max_depth=6, integrator=oracle.INTEGRATOR_LIT))
+    assert want["stats"]["textured_hits"] > 0 and want["stats"]["shadow_rays"] > 0
+    params = capi.default_params(max_depth=6, integrator=capi.INTEGRATOR_LIT)
+    a, b = gpu_ctx_factory(), gpu_ctx_factory()
+    assert a.get_option(capi.OPTION_TEXEL_SETS) == 1
+    b.set_option(capi.OPTION_TEXEL_SETS, 0)
+    with pytest.raises(capi.PtxError):
+        b.set_option(capi.OPTION_TEXEL_SETS, 2)
+    for ctx, label in ((a, "texel sets on"), (b, "texel sets off")):
+        upload(ctx, ing, oracle, options=opts, with_material_ext=True)
+        ctx.reset_stats()
+        got = gpu_render(ctx, oracle, cam, 144, 144, 2, params=params)
+        assert_images_bit_equal(got, want, "lit stress scene, " + label)
+        st = ctx.stats()
+        assert st["rays"] == want["stats"]["rays"] and st["hits"] == want["stats"]["hits"] and st["shadow_rays"] == want["stats"]["shadow_rays"]
+    # toggled on live contexts: a without, b with its sets from now on
+    a.set_option(capi.OPTION_TEXEL_SETS, 0)
+    b.set_option(capi.OPTION_TEXEL_SETS, 1)
+    for ctx, label in ((a, "switched off"), (b, "switched on")):
+        assert_images_bit_equal(gpu_render(ctx, oracle, cam, 144, 144, 2, params=params), want, "lit stress scene, texel sets " + label)
+    # the reference integrator never builds or reads a set
+    want_ref = sc.render(cam, 96, 96, 1, SEED, params=oracle.default_params(max_depth=4))
+    assert_images_bit_equal(gpu_render(b, oracle, cam, 96, 96, 1, params=capi.default_params(max_depth=4)), want_ref, "reference integrator beside texel sets")
+
+
 def test_extension_error_paths(gpu_ctx_factory):
     from path_tracer_amd import capi
     ctx = gpu_ctx_factory()
