@@ -4,8 +4,8 @@
   python bench.py --gpus N --steps K --warmup W
 
 One process per GPU (torch.distributed / RCCL when N > 1, launched by torch.distributed.run).
-A "step" = one pass of the hot path over one batch: --spp-per-step (default 16) samples per pixel of
-the whole 1920x1080 image = 33.2 M pixel-samples, through the reference-mirroring host
+A "step" = one pass of the hot path over one batch: --spp-per-step (default 32) samples per pixel of
+the whole 1920x1080 image = 66.4 M pixel-samples, through the reference-mirroring host
 (path_tracer_amd.host.Renderer -> C ABI -> HIP kernels).  Multi-GPU is the spp partition of
 BASELINE.json: every rank holds the full scene + BVH, renders its own sample indices
 (rng_sample_offset) into its own accumulation buffer, and the buffers are combined by ONE RCCL
@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--spp-per-step", type=int, default=32)
     ap.add_argument("--workload", default="sponza_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--max-depth", type=int, default=16)
     ap.add_argument("--integrator", default="reference", choices=["reference", "lit"],

@@ -277,7 +277,7 @@ typedef enum {
                                           fused launch; 0: never; 65536                                                    [PTX_TAIL_RAYS] */
     PTX_OPTION_TAIL_SHIFT = 3,         /* ... or at or below chunk paths >> shift; 7                                       [PTX_TAIL_SHIFT] */
     PTX_OPTION_TARGET_PATHS = 4,       /* paths per chunk of a batch (48 + 24 B of queue state each, per frame in flight);
-                                          33 554 432                                                                       [PTX_TARGET_PATHS] */
+                                          67 108 864                                                                       [PTX_TARGET_PATHS] */
     PTX_OPTION_MATERIAL_SORT = 5,      /* lit integrator: group each bounce's queue by material class before shading
                                           (measured 30 - 49 % slower); 0                              [PTX_MATERIAL_SORT] */
     PTX_OPTION_EXTEND_WAVES = 6,       /* waves of the persistent traversal grid; 0 = what the device holds (default)      [PTX_EXTEND_WAVES] */

@@ -155,7 +155,7 @@ struct ptx_context {
     float4 *d_albedo = nullptr, *d_normal = nullptr; float *d_depth = nullptr; uint2 *d_ids = nullptr;
 
     // wavefront state
-    uint64_t target_paths = 32u << 20;
+    uint64_t target_paths = 64u << 20;        // paths per chunk (PTX_OPTION_TARGET_PATHS): 64 Mi x 120 B = 7.7 GB of queue state per set in flight (lit: 176 B); 32 Mi measured 1.3 - 1.8 % slower, 128 Mi another 1 % faster on the lit workload only
     uint32_t extend_waves = 4096;           // persistent grid of the traversal kernel
     PathSet sets[kMaxSets];
     int n_sets = 2;                         // chunks in flight (PTX_FRAMES_IN_FLIGHT; measured: 2 gives the whole gain, 3 is slower than 2 and 4)

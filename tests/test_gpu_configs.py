@@ -247,7 +247,7 @@ def test_options_are_per_context_and_change_no_bit(oracle, gpu_ctx_factory):
     cam = oracle.camera_matrices([0, 1.0, 3.9], oracle.yaw_quat(0), np.deg2rad(np.float32(40)), 160 / 120, 0.1, 1000.0)
     a, b = gpu_ctx_factory(), gpu_ctx_factory()
     assert a.get_option(capi.OPTION_FRAMES_IN_FLIGHT) == 2 and a.get_option(capi.OPTION_TAIL_RAYS) == 65536
-    assert a.get_option(capi.OPTION_TARGET_PATHS) == 32 << 20 and a.get_option(capi.OPTION_SHADE_GRID) == 8192
+    assert a.get_option(capi.OPTION_TARGET_PATHS) == 64 << 20 and a.get_option(capi.OPTION_SHADE_GRID) == 8192
     for key, value in ((capi.OPTION_FRAMES_IN_FLIGHT, 4), (capi.OPTION_TARGET_PATHS, 160 * 120 * 3), (capi.OPTION_TAIL_RAYS, 0),
                        (capi.OPTION_TAIL_SHIFT, 3), (capi.OPTION_EXTEND_WAVES, 640), (capi.OPTION_SHADE_GRID, 64)):
         b.set_option(key, value)

@@ -3,7 +3,7 @@
 #   1. kernel trace + stats of `bench.py --steps 2 --warmup 1` (the bench command, shortened)
 #   2. PMC passes, one rocprofv3 run each (never combined with tracing domains other than the kernel trace):
 #      FETCH_SIZE | WRITE_SIZE + TCC hit/miss | SQ issue counters | SQ memory counters   on tools/prof_run.py 2
-#      SQ VALU-utilisation counters, VALU instruction mix by type                       on tools/prof_run.py 16
+#      SQ VALU-utilisation counters, VALU instruction mix by type                       on tools/prof_run.py 32
 #   3. summaries -> gpurun_out/prof_<tag>/*.json (copy the ones to keep into profiles/)
 TAG=${1:-r01}
 INTEG=${2:-reference}      # "lit": the same passes over bench.py --integrator lit (k_shade_lit, the any-hit traversal)
@@ -17,6 +17,6 @@ for pass in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INST
   timeout -s KILL 120 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/pmc_$name -- python3 tools/prof_run.py 2 $INTEG > $OUT/pmc_$name.log 2>&1 || { echo "pass $name failed" >> $OUT/errors.log; exit 1; }
 done
 mkdir -p $OUT/valu
-timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/valu/pmc_a -- python3 tools/prof_run.py 16 $INTEG > $OUT/valu/a.log 2>&1 || { echo "valu pass failed" >> $OUT/errors.log; exit 1; }
-timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT64 --kernel-trace --output-format csv -d $OUT/valu/pmc_b -- python3 tools/prof_run.py 16 $INTEG > $OUT/valu/b.log 2>&1 || { echo "valu mix pass failed" >> $OUT/errors.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/valu/pmc_a -- python3 tools/prof_run.py 32 $INTEG > $OUT/valu/a.log 2>&1 || { echo "valu pass failed" >> $OUT/errors.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT64 --kernel-trace --output-format csv -d $OUT/valu/pmc_b -- python3 tools/prof_run.py 32 $INTEG > $OUT/valu/b.log 2>&1 || { echo "valu mix pass failed" >> $OUT/errors.log; exit 1; }
 python3 tools/profile_round_summary.py $OUT $TAG $INTEG

@@ -39,7 +39,7 @@ vp = json.loads(subprocess.check_output([sys.executable, os.path.join(here, "pmc
 mix_path = os.path.join(os.path.dirname(here), "profiles", "r03_isa_mix.json")
 static_mix = json.load(open(mix_path))["kernels"] if os.path.exists(mix_path) else {}
 valu = {"workload": WORKLOAD, "csrc_sha16": SRC_HASH,
-        "source": "rocprofv3 --pmc, two passes over tools/prof_run.py 16 (one 16-spp batch, the bench's launch size): SQ_WAVES SQ_WAVE_CYCLES "
+        "source": "rocprofv3 --pmc, two passes over tools/prof_run.py 32 (one 32-spp batch, the bench's launch size): SQ_WAVES SQ_WAVE_CYCLES "
                   "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY | SQ_INSTS_VALU "
                   "and its _FMA_F32 _ADD_F32 _MUL_F32 _CVT _INT32 _TRANS_F32 _INT64 breakdown; round tag %s" % tag,
         "definitions": "cycles = GRBM_GUI_ACTIVE / 8 XCDs.  Issue model measured on this chip (profiles/r02_valu_calibration.json): a SIMD has two vector "
