@@ -284,11 +284,12 @@ typedef enum {
     PTX_OPTION_SHADE_GRID = 7,         /* most blocks a shading launch starts; 0 = library default, 8192                   [PTX_SHADE_GRID] */
     PTX_OPTION_HOST_REFIT = 8,         /* 1: ptx_update_instances never refits on the device; 0                            [PTX_HOST_REFIT] */
     PTX_OPTION_REFIT_VERIFY = 9,       /* 1: every device refit is compared with a host refit (tests); 0                   [PTX_REFIT_VERIFY] */
-    PTX_OPTION_TEXEL_SETS = 10         /* lit integrator: 1 (default) interleaves the base colour / normal / metallic-roughness
+    PTX_OPTION_TEXEL_SETS = 10,        /* lit integrator: 1 (default) interleaves the base colour / normal / metallic-roughness
                                           textures of a material (same size, same wrap and filter) into one array with one entry
                                           per fetch position -- one or two 16-byte loads per hit instead of up to twelve; costs up
                                           to 32 B per texel of device memory per such material, built on the first lit frame;
                                           0: the textures are fetched one by one                                              [PTX_TEXEL_SETS] */
+    PTX_OPTION_TEXEL_SET_BYTES = 11    /* read-only (ptx_get_option): device memory the context's texel sets hold, in bytes */
 } ptx_option;
 int ptx_set_option(ptx_context *ctx, int key, uint64_t value);
 int ptx_get_option(ptx_context *ctx, int key, uint64_t *value);

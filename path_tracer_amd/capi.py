@@ -84,7 +84,8 @@ EXPORTS = [
 ]
 # ptx_option (include/ptx.h)
 (OPTION_FRAMES_IN_FLIGHT, OPTION_TAIL_RAYS, OPTION_TAIL_SHIFT, OPTION_TARGET_PATHS, OPTION_MATERIAL_SORT,
- OPTION_EXTEND_WAVES, OPTION_SHADE_GRID, OPTION_HOST_REFIT, OPTION_REFIT_VERIFY, OPTION_TEXEL_SETS) = range(1, 11)
+ OPTION_EXTEND_WAVES, OPTION_SHADE_GRID, OPTION_HOST_REFIT, OPTION_REFIT_VERIFY, OPTION_TEXEL_SETS,
+ OPTION_TEXEL_SET_BYTES) = range(1, 12)
 
 _lib = None
 

@@ -1389,6 +1389,7 @@ int ptx_set_option(ptx_context *c, int key, uint64_t value)
         if (value > 1) return fail(c, PTX_ERR_INVALID, "ptx_set_option: texel sets are 0 or 1");
         if (c->texel_sets_on != (value != 0)) { c->texel_sets_on = value != 0; c->texel_sets_stale = true; }   // the next lit frame re-writes the material rows
         return PTX_OK;
+    case PTX_OPTION_TEXEL_SET_BYTES: return fail(c, PTX_ERR_INVALID, "ptx_set_option: the texel set size is read-only");
     default: return fail(c, PTX_ERR_INVALID, "ptx_set_option: unknown option key");
     }
 }
@@ -1408,6 +1409,7 @@ int ptx_get_option(ptx_context *c, int key, uint64_t *value)
     case PTX_OPTION_HOST_REFIT: *value = c->host_refit_only ? 1 : 0; return PTX_OK;
     case PTX_OPTION_REFIT_VERIFY: *value = c->refit_verify ? 1 : 0; return PTX_OK;
     case PTX_OPTION_TEXEL_SETS: *value = c->texel_sets_on ? 1 : 0; return PTX_OK;
+    case PTX_OPTION_TEXEL_SET_BYTES: *value = c->texel_set_bytes; return PTX_OK;
     default: return fail(c, PTX_ERR_INVALID, "ptx_get_option: unknown option key");
     }
 }

@@ -200,11 +200,16 @@ def test_texel_sets_every_mode_against_oracle_and_plain_taps(oracle, gpu_ctx_fac
         assert_images_bit_equal(got, want, "lit stress scene, " + label)
         st = ctx.stats()
         assert st["rays"] == want["stats"]["rays"] and st["hits"] == want["stats"]["hits"] and st["shadow_rays"] == want["stats"]["shadow_rays"]
+    # a really built sets (bilinear 32 / 16 B and nearest 8 B per fetch position of these tiny textures), b none
+    assert 2000 < a.get_option(capi.OPTION_TEXEL_SET_BYTES) < 200000 and b.get_option(capi.OPTION_TEXEL_SET_BYTES) == 0
+    with pytest.raises(capi.PtxError):
+        a.set_option(capi.OPTION_TEXEL_SET_BYTES, 0)
     # toggled on live contexts: a without, b with its sets from now on
     a.set_option(capi.OPTION_TEXEL_SETS, 0)
     b.set_option(capi.OPTION_TEXEL_SETS, 1)
     for ctx, label in ((a, "switched off"), (b, "switched on")):
         assert_images_bit_equal(gpu_render(ctx, oracle, cam, 144, 144, 2, params=params), want, "lit stress scene, texel sets " + label)
+    assert b.get_option(capi.OPTION_TEXEL_SET_BYTES) == a.get_option(capi.OPTION_TEXEL_SET_BYTES) > 0
     # the reference integrator never builds or reads a set
     want_ref = sc.render(cam, 96, 96, 1, SEED, params=oracle.default_params(max_depth=4))
     assert_images_bit_equal(gpu_render(b, oracle, cam, 96, 96, 1, params=capi.default_params(max_depth=4)), want_ref, "reference integrator beside texel sets")

@@ -30,7 +30,7 @@ def test_option_keys_match_the_header():
     from path_tracer_amd import capi
     header = open(os.path.join(ROOT, "include", "ptx.h")).read()
     enum = dict((k, int(v)) for k, v in re.findall(r"(PTX_OPTION_[A-Z_]+) = (\d+)", header))
-    assert len(enum) == 10
+    assert len(enum) == 11
     for name, value in enum.items():
         assert getattr(capi, name[4:]) == value, name
     L = capi.load()
