@@ -92,6 +92,10 @@ def main():
     ap.add_argument("--traffic-json", default=None,
                     help="PMC-derived HBM traffic of the traversal kernel (default: profiles/traffic.json, or traffic_lit.json for "
                          "--integrator lit); valu*.json is read from the same directory")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: bring up the RCCL process group for the one rank anyway, so that every collective of the "
+                         "N > 1 path (barrier, reduce of the accumulation buffer, gathers of the per-rank timings) really runs "
+                         "through RCCL on a one-GPU box; the line then says n_gpus 1 with a collective_backend")
     ap.add_argument("--launch-check", action="store_true",
                     help="only bring up the N ranks, check the world size with one all-reduce and print a JSON line; no "
                          "GPU is touched when combined with --rehearse-gloo (the CPU test of the launcher path)")
@@ -114,7 +118,13 @@ def main():
 
     import torch
     dist = None
-    if world > 1:
+    if world == 1 and args.force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         if args.rehearse_gloo:
             local_rank = 0

@@ -435,6 +435,28 @@ def test_bench_two_rank_rehearsal_reduce_leg():
     assert d["time_to_image_ms"] >= d["render_ms"]["max"]
 
 
+def test_bench_one_rank_through_rccl():
+    """bench.py --gpus 1 --force-dist: the process group of the N > 1 path brought up over RCCL for ONE rank, so that the
+    collectives the multi-GPU line depends on -- barrier, the reduce of the 1080p-sized accumulation tensor (the untimed warm-up
+    call), the gathers of the per-rank timings, the max / sum all-reduces -- really execute in librccl on this box's GPU
+    (two ranks on one device is what RCCL refuses, one rank it takes).  The line must equal a plain N = 1 run's shape."""
+    import json
+    import subprocess
+    import sys
+    from helpers import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--workload", "cornell_512",
+                        "--steps", "2", "--warmup", "1", "--spp-per-step", "2", "--max-depth", "8", "--cpu-baseline-spp", "0",
+                        "--verify-reduce"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["collective_backend"] == "nccl (RCCL)"
+    assert d["reduce_check"]["rel_mse_vs_single_context"] < 1e-12, d["reduce_check"]
+    assert len(d["render_ms"]["per_rank"]) == 1 and d["reduce_ms"] >= 0 and d["value"] > 0
+
+
 def test_bench_fixed_budget_mode_two_ranks_and_one(tmp_path):
     """bench.py --total-spp S (BASELINE.json configs 3 / 5: a fixed sample budget partitioned over the GPUs): S = 10 spp
     split over two ranks (5 each, as batches of 3 + 2), time-to-image including the reduce, "scaling": "strong"; the
