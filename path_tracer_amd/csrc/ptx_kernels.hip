@@ -28,7 +28,7 @@ constexpr int kExtendBlock = 64;    // one wave per workgroup: resources free as
 #ifndef PTX_SHADE_BLOCK
 #define PTX_SHADE_BLOCK 512
 #endif
-constexpr int kShadeBlock = PTX_SHADE_BLOCK;   // one queue-tail atomic per block (a single word takes only ~88 M atomics/s); 512 threads x 89 VGPRs = 5 waves/SIMD
+constexpr int kShadeBlock = PTX_SHADE_BLOCK;   // one queue-tail atomic per block (a single word takes only ~88 M atomics/s); 512 threads x 99 VGPRs = 4 waves/SIMD (256 and 1024 threads measured slower)
 #ifndef PTX_LIT_BLOCK
 #define PTX_LIT_BLOCK 256
 #endif

@@ -130,7 +130,9 @@ extern "C" int ptx_reduce_accumulation(ptx_context **ctxs, int n, int root)
     bool shared_device = false;
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < i; ++j) shared_device = shared_device || devs[j] == devs[i];
-    if (n == 1) return ptx_synchronize(rc);
+    // one context: nothing to combine -- unless PTX_RCCL_SINGLE_RANK is set (tests): then the whole sequence below runs with a
+    // one-rank communicator, which is how a one-GPU box exercises the REAL librccl through this file's dlsym'd prototypes
+    if (n == 1 && !getenv("PTX_RCCL_SINGLE_RANK")) return ptx_synchronize(rc);
 
     // every return path below leaves the caller's current device as it was (ptx_synchronize binds each context's)
     int caller_device = 0;

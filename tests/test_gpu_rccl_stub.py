@@ -13,6 +13,35 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _child_real_one_rank():
+    """One context, PTX_RCCL_SINGLE_RANK set: the real librccl, loaded by dlopen, driven through the prototypes and enum
+    values csrc/ptx_rccl.cpp declares by hand -- ncclCommInitAll for [0], a group of one ncclReduce (fp32 sum, in place),
+    ncclCommDestroy with the context.  The image must come back unchanged (mean of one mean), twice (cached communicator)."""
+    import numpy as np
+    import torch  # noqa: F401
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    from helpers import cornell, gpu_render, upload
+    from oracle import pyoracle as oracle
+    from path_tracer_amd import capi
+    cam = oracle.camera_matrices([0, 1.0, 3.9], oracle.yaw_quat(0), np.deg2rad(np.float32(40)), 1.0, 0.1, 1000.0)
+    a = capi.Context(0)
+    upload(a, cornell(), oracle)
+    want = gpu_render(a, oracle, cam, 96, 96, 4, params=capi.default_params(max_depth=6))["albedo"]
+    for _ in range(2):
+        capi.reduce_accumulation([a], root=0)
+        got = a.read_image(capi.IMAGE_ALBEDO)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert torch.cuda.current_device() == 0
+    a.close()
+    b = capi.Context(0)                      # a fresh context after the communicator went with the last one
+    upload(b, cornell(), oracle)
+    want = gpu_render(b, oracle, cam, 96, 96, 2, params=capi.default_params(max_depth=6))["albedo"]
+    capi.reduce_accumulation([b], root=0)
+    assert np.array_equal(b.read_image(capi.IMAGE_ALBEDO).view(np.uint32), want.view(np.uint32))
+    b.close()
+
+
 def _child(with_stub):
     import ctypes as C
 
@@ -104,6 +133,21 @@ def test_reduce_accumulation_communicator_cache_against_stub(with_stub):
     assert "rccl stub check ok" in p.stdout
 
 
+@pytest.mark.gpu
+def test_reduce_accumulation_one_rank_through_real_rccl():
+    """What the stand-in cannot show, as far as one GPU goes: librccl itself behind ptx_reduce_accumulation (one rank)."""
+    env = dict(os.environ)
+    env.pop("PTX_RCCL_LIB", None)
+    env["PTX_RCCL_SINGLE_RANK"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "real1"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "rccl stub check ok" in p.stdout
+
+
 if __name__ == "__main__":
-    _child(sys.argv[1] == "stub")
+    if sys.argv[1] == "real1":
+        _child_real_one_rank()
+    else:
+        _child(sys.argv[1] == "stub")
     print("rccl stub check ok")
