@@ -110,7 +110,8 @@ typedef struct {
                                      metallic = metallicFactor x B at the hit's uv (lit integrator only) */
     uint32_t normal_texture;      /* glTF normalTexture as bindless index + 1 (0: none), a LINEAR texture: tangent-space
                                      normal = texel x 2 - 1, +Y up; the tangent frame is derived per triangle from its
-                                     world-space positions and uvs (the vertex format has no tangent); scale taken as 1 */
+                                     world-space positions and uvs (the vertex format has no tangent); glTF's
+                                     normalTexture.scale: ptx_set_material_normal_scale */
     uint32_t emissive_texture;    /* glTF emissiveTexture as bindless index + 1 (0: none): emitted radiance = emissive x texel
                                      at the point's uv -- at a hit and at a light sample; the light table still picks
                                      triangles by area x luminance(emissive) (lit integrator only).  The texel is decoded the
@@ -192,6 +193,9 @@ int ptx_add_material(ptx_context *ctx, const ptx_material *material, uint32_t *i
 /* Build extension: extended properties of material `index` (see ptx_material_ext).  Takes effect at the next
  * ptx_set_instances.  No counterpart in the reference. */
 int ptx_set_material_ext(ptx_context *ctx, uint32_t index, const ptx_material_ext *ext);
+/* Build extension: glTF normalTexture.scale of material `index` (default 1): x and y of the tangent-space normal are
+ * multiplied by it before the normal is put together (lit integrator).  Finite values only. */
+int ptx_set_material_normal_scale(ptx_context *ctx, uint32_t index, float scale);
 /* Build extension: bitwise OR of ptx_scene_option; takes effect at the next ptx_set_instances. */
 int ptx_set_scene_options(ptx_context *ctx, uint32_t options);
 

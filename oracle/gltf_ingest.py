@@ -142,6 +142,7 @@ class IngestedScene:
         self.indices = np.zeros(0, dtype=np.uint32)
         self.materials = np.zeros(0, dtype=MATERIAL_DTYPE)
         self.material_ext = np.zeros(0, dtype=MATERIAL_EXT_DTYPE)
+        self.normal_scale = np.zeros(0, dtype=np.float32)
         self.textures = []          # list of (rgba8 HxWx4 uint8, srgb flag)
         self.texture_lookup = {}    # ident -> bindless index   (renderer.rs:867-873)
         self.geometries = {}        # ident -> (id, v_first, v_count, i_first, i_count)
@@ -158,12 +159,13 @@ class IngestedScene:
         self.indices = np.concatenate([self.indices, i.astype(np.uint32)])
         return first
 
-    def add_material(self, m, ext=None):
+    def add_material(self, m, ext=None, normal_scale=1.0):
         self.materials = np.concatenate([self.materials, m])
         if ext is None:
             ext = np.zeros(1, dtype=MATERIAL_EXT_DTYPE)
             ext["ior"] = 1.5
         self.material_ext = np.concatenate([self.material_ext, ext])
+        self.normal_scale = np.concatenate([self.normal_scale, np.float32([normal_scale])])    # glTF normalTexture.scale
         return len(self.materials) - 1
 
     def import_gltf(self, path, position_offset=(0.0, 0.0, 0.0), decode_image=None):
@@ -258,6 +260,7 @@ class IngestedScene:
         m = np.zeros(1, dtype=MATERIAL_DTYPE)
         ext = np.zeros(1, dtype=MATERIAL_EXT_DTYPE)
         ext["ior"] = 1.5
+        normal_scale = 1.0
         pbr = {}
         if mat_idx is not None:
             gm = doc["materials"][mat_idx]
@@ -285,7 +288,9 @@ class IngestedScene:
                 t = doc["materials"][mat_idx].get(key)
                 if t is not None and os.path.exists(os.path.join(base, doc["images"][doc["textures"][t["index"]]["source"]]["uri"])):
                     ext[field] = self._texture_from_gltf(doc, t, base, decode_image, srgb=srgb) + 1
-        return self.add_material(m, ext)
+                    if key == "normalTexture":
+                        normal_scale = float(t.get("scale", 1.0))
+        return self.add_material(m, ext, normal_scale)
 
     def instances(self, xform_fn):
         """renderer.rs:912-955: one Offsets row + TLAS instance per entity, in push order.

@@ -967,7 +967,9 @@ static void raygen_pixel_lit(job_t *j, uint32_t x, uint32_t y)
                  * orthogonal to the shading normal.  A degenerate uv mapping, or a perturbed normal that ends up below
                  * the geometric surface, leaves the shading normal as it is. */
                 v3 tn = sample_texture(&d->textures[e->normal_texture - 1], tu, tv);
-                float mx = tn.x * 2.0f - 1.0f, my = tn.y * 2.0f - 1.0f, mz = tn.z * 2.0f - 1.0f;
+                /* glTF: scaledNormal = normalize((texel * 2 - 1) * vec3(scale, scale, 1)) */
+                const float nsc = s->d.normal_scale ? s->d.normal_scale[off->material_offset] : 1.0f;
+                float mx = (tn.x * 2.0f - 1.0f) * nsc, my = (tn.y * 2.0f - 1.0f) * nsc, mz = tn.z * 2.0f - 1.0f;
                 v3 e1 = v3_sub(wt->b, wt->a), e2 = v3_sub(wt->c, wt->a);
                 float du1 = v1->uv[0] - v0->uv[0], dv1 = v1->uv[1] - v0->uv[1];
                 float du2 = v2->uv[0] - v0->uv[0], dv2 = v2->uv[1] - v0->uv[1];

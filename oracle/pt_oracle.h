@@ -88,7 +88,8 @@ typedef struct {
                                B the metallic factor (lit integrator) */
     uint32_t normal_texture;   /* glTF normalTexture: texture index + 1, 0 = none; a LINEAR texture holding a tangent-space normal
                                   (x, y, z) = texel * 2 - 1, +Y up; the tangent frame is derived per triangle from its world-space
-                                  positions and uvs (lit integrator; normalTexture.scale is taken as 1) */
+                                  positions and uvs; x and y are multiplied by orc_scene_desc.normal_scale (glTF
+                                  normalTexture.scale) before the normal is put together (lit integrator) */
     uint32_t emissive_texture; /* glTF emissiveTexture: texture index + 1, 0 = none; emitted radiance = emissive x texel (lit
                                   integrator); the light table still picks triangles by area x luminance(emissive) */
 } orc_material_ext;
@@ -123,6 +124,7 @@ typedef struct {
     const orc_texture *textures;   uint64_t n_textures;
     const orc_material_ext *material_ext;   /* n_materials rows, or NULL: no emission, no transmission */
     uint64_t options;                       /* ORC_SCENE_* */
+    const float *normal_scale;              /* glTF normalTexture.scale per material (n_materials), or NULL: 1 */
 } orc_scene_desc;
 
 typedef struct orc_scene orc_scene;

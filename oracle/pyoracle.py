@@ -53,7 +53,7 @@ class SceneDesc(C.Structure):
                 ("materials", C.c_void_p), ("n_materials", C.c_uint64),
                 ("instances", C.c_void_p), ("n_instances", C.c_uint64),
                 ("textures", C.c_void_p), ("n_textures", C.c_uint64),
-                ("material_ext", C.c_void_p), ("options", C.c_uint64)]
+                ("material_ext", C.c_void_p), ("options", C.c_uint64), ("normal_scale", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -67,8 +67,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
+        build()          # no-op unless the library is missing or older than its sources (a stale one would silently ignore new
+                         # fields of the scene description)
         L = C.CDLL(_LIB_PATH)
         L.orc_scene_create.restype = C.c_void_p
         L.orc_scene_create.argtypes = [C.POINTER(SceneDesc)]
@@ -145,7 +145,7 @@ def yaw_quat(yaw_deg):
 class OracleScene:
     """Owns the numpy arrays an orc_scene points into."""
 
-    def __init__(self, vertices, indices, materials, instances, textures=(), material_ext=None, options=0):
+    def __init__(self, vertices, indices, materials, instances, textures=(), material_ext=None, options=0, normal_scale=None):
         self.vertices = np.ascontiguousarray(vertices, dtype=VERTEX_DTYPE)
         self.indices = np.ascontiguousarray(indices, dtype=np.uint32)
         self.materials = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
@@ -158,10 +158,15 @@ class OracleScene:
         if material_ext is not None:
             self.material_ext = np.ascontiguousarray(material_ext, dtype=MATERIAL_EXT_DTYPE)
             assert len(self.material_ext) == len(self.materials)
+        self.normal_scale = None
+        if normal_scale is not None:
+            self.normal_scale = np.ascontiguousarray(normal_scale, dtype=np.float32)
+            assert len(self.normal_scale) == len(self.materials)
         d = SceneDesc(self.vertices.ctypes.data, len(self.vertices), self.indices.ctypes.data, len(self.indices),
                       self.materials.ctypes.data, len(self.materials), self.instances.ctypes.data,
                       len(self.instances), C.addressof(self.tex_structs), len(textures),
-                      self.material_ext.ctypes.data if self.material_ext is not None else None, options)
+                      self.material_ext.ctypes.data if self.material_ext is not None else None, options,
+                      self.normal_scale.ctypes.data if self.normal_scale is not None else None)
         self.handle = lib().orc_scene_create(C.byref(d))
 
     def __del__(self):
@@ -217,4 +222,5 @@ def scene_from_ingest(ing, options=0, with_material_ext=False):
     """IngestedScene -> OracleScene with the reference's per-entity instance list."""
     inst = ing.instances(transform_matrix)
     return OracleScene(ing.vertices, ing.indices, ing.materials, inst, ing.textures,
-                       material_ext=ing.material_ext if with_material_ext else None, options=options)
+                       material_ext=ing.material_ext if with_material_ext else None, options=options,
+                       normal_scale=getattr(ing, "normal_scale", None) if with_material_ext else None)

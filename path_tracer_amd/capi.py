@@ -79,7 +79,7 @@ EXPORTS = [
     "ptx_set_instances", "ptx_resize", "ptx_render", "ptx_render_batch", "ptx_read_image", "ptx_write_albedo",
     "ptx_export_albedo_device", "ptx_import_albedo_device", "ptx_reduce_accumulation", "ptx_synchronize",
     "ptx_set_profiling", "ptx_get_stats", "ptx_reset_stats", "ptx_last_error",
-    "ptx_set_material_ext", "ptx_set_scene_options", "ptx_update_instances", "ptx_render_static",
+    "ptx_set_material_ext", "ptx_set_material_normal_scale", "ptx_set_scene_options", "ptx_update_instances", "ptx_render_static",
     "ptx_set_option", "ptx_get_option",
 ]
 # ptx_option (include/ptx.h)
@@ -138,6 +138,7 @@ def load():
     L.ptx_last_error.argtypes = [vp]
     L.ptx_last_error.restype = C.c_char_p
     L.ptx_set_material_ext.argtypes = [vp, C.c_uint32, vp]
+    L.ptx_set_material_normal_scale.argtypes = [vp, C.c_uint32, C.c_float]
     L.ptx_set_scene_options.argtypes = [vp, C.c_uint32]
     L.ptx_set_option.argtypes = [vp, C.c_int, C.c_uint64]
     L.ptx_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64)]
@@ -216,6 +217,9 @@ class Context:
     def set_material_ext(self, index, ext):
         e = np.ascontiguousarray(ext, dtype=MATERIAL_EXT_DTYPE).reshape(1)
         self._check(self._L.ptx_set_material_ext(self.handle, index, e.ctypes.data))
+
+    def set_material_normal_scale(self, index, scale):
+        self._check(self._L.ptx_set_material_normal_scale(self.handle, int(index), float(scale)))
 
     def set_scene_options(self, options):
         self._check(self._L.ptx_set_scene_options(self.handle, options))

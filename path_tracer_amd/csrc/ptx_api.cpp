@@ -110,6 +110,7 @@ struct ptx_context {
     std::vector<uint32_t> indices;
     std::vector<ptx_material> materials;
     std::vector<ptx_material_ext> material_ext;   // build extension: one row per material
+    std::vector<float> normal_scale;              // glTF normalTexture.scale, one per material (ptx_set_material_normal_scale)
     uint32_t scene_options = 0;                   // ptx_scene_option bits
     std::vector<Geometry> geometries;
     std::vector<TexDesc> textures;          // device texel pointers
@@ -529,6 +530,17 @@ int ptx_add_material(ptx_context *c, const ptx_material *m, uint32_t *index)
     c->materials.push_back(*m);
     ptx_material_ext e; memset(&e, 0, sizeof e); e.ior = 1.5f;
     c->material_ext.push_back(e);
+    c->normal_scale.push_back(1.0f);
+    c->materials_dirty = true;
+    return PTX_OK;
+}
+
+int ptx_set_material_normal_scale(ptx_context *c, uint32_t index, float scale)
+{
+    if (!c) return PTX_ERR_INVALID;
+    if (index >= c->materials.size()) return fail(c, PTX_ERR_INVALID, "ptx_set_material_normal_scale: material index out of range");
+    if (!std::isfinite(scale)) return fail(c, PTX_ERR_INVALID, "ptx_set_material_normal_scale: scale must be finite");
+    c->normal_scale[index] = scale;
     c->materials_dirty = true;
     return PTX_OK;
 }
@@ -855,7 +867,8 @@ static int set_instances_impl(ptx_context *c, const ptx_instance *inst, uint32_t
         lm.transmission = c->material_ext[i].transmission; lm.ior = c->material_ext[i].ior;
         lm.mr_texture = c->material_ext[i].mr_texture;
         lm.normal_texture = c->material_ext[i].normal_texture; lm.emissive_texture = c->material_ext[i].emissive_texture;
-        lm._pad = c->materials[i].has_base_texture ? (uint64_t)c->materials[i].base_texture_indice + 1u : 0u;   // the base colour slot the ShadeRecs of this build carry (host-side note for ensure_texel_sets; no kernel reads it)
+        lm.base_slot = c->materials[i].has_base_texture ? c->materials[i].base_texture_indice + 1u : 0u;
+        lm.normal_scale = c->normal_scale[i];
     }
 
     lap("lights");
@@ -998,7 +1011,7 @@ static int ensure_texel_sets(ptx_context *c)
     const size_t n = rows.size();
     for (size_t i = 0; c->texel_sets_on && i < n; ++i) {
         LitMaterial &lm = rows[i];
-        const uint32_t slot[3] = {(uint32_t)lm._pad, lm.normal_texture, lm.mr_texture};   // as of the build the device scene comes from
+        const uint32_t slot[3] = {lm.base_slot, lm.normal_texture, lm.mr_texture};   // as of the build the device scene comes from
         uint32_t present = 0, w = 0, h = 0, mode = 0;
         bool ok = true;
         for (int k = 0; k < 3 && ok; ++k) {

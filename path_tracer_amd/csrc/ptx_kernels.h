@@ -64,7 +64,8 @@ struct alignas(16) LitMaterial {
     uint32_t set_flags;
     uint32_t set_wh;     // width | height << 16 of the set's textures
     const uint32_t *set_texels;
-    uint64_t _pad;
+    float normal_scale;  // glTF normalTexture.scale
+    uint32_t base_slot;  // host-side note (ensure_texel_sets): the base colour texture slot (index + 1) the ShadeRecs of this build carry; no kernel reads it
 };
 static_assert(sizeof(LitMaterial) == 64, "LitMaterial must be 64 bytes");
 // Texel sets (lit integrator, built by ptx_api.cpp: ensure_texel_sets).  A hit of the lit integrator reads up to three

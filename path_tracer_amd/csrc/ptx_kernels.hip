@@ -1092,7 +1092,7 @@ __device__ __forceinline__ void lit_shade_hit(const SceneDev &sc, const FrameDev
         // triangle -- T along dP/du, B along -dP/dv, both made orthogonal to the shading normal; a degenerate uv
         // mapping or a perturbed normal below the geometric surface leaves the shading normal as it is
         const f3 tn = tap_resolve(tap_n, s_lut);
-        const float mx = tn.x * 2.0f - 1.0f, my = tn.y * 2.0f - 1.0f, mz = tn.z * 2.0f - 1.0f;
+        const float mx = (tn.x * 2.0f - 1.0f) * lm.normal_scale, my = (tn.y * 2.0f - 1.0f) * lm.normal_scale, mz = tn.z * 2.0f - 1.0f;   // glTF normalTexture.scale
         const f3 e1 = vb - va, e2 = vc - va;
         const float du1 = s2.w - s2.y, dv1 = s3.x - s2.z, du2 = s3.y - s2.y, dv2 = s3.z - s2.z;
         const float det = du1 * dv2 - du2 * dv1;

@@ -181,6 +181,7 @@ Material material_from_gltf(const Json &doc, const Json *gltf_mat, Renderer &ren
                 if (FILE *probe = fopen(path.c_str(), "rb")) {
                     fclose(probe);
                     *mp.field = texture_from_gltf(doc, *t, renderer, gltf_dir, mp.srgb).bindless_indice + 1u;
+                    if (mp.field == &m.normal_texture) m.normal_scale = (float)t->get_number("scale", 1.0);
                 }
             }
     }
@@ -205,6 +206,7 @@ Material material_from_gltf(const Json &doc, const Json *gltf_mat, Renderer &ren
     memcpy(ext.emissive, m.emissive, 12); ext.transmission = m.transmission; ext.ior = m.ior;
     ext.mr_texture = m.mr_texture; ext.normal_texture = m.normal_texture; ext.emissive_texture = m.emissive_texture;
     renderer.scene.set_material_ext(m.shared_buffer_index, ext);
+    if (m.normal_scale != 1.0f) renderer.scene.set_material_normal_scale(m.shared_buffer_index, m.normal_scale);
     return m;
 }
 
@@ -257,6 +259,11 @@ void Scene::set_material_ext(uint64_t index, const ptx_material_ext &e)
     if (ptx_set_material_ext(ctx_, (uint32_t)index, &e)) ptx_throw(ctx_, "set_material_ext");
     if (material_ext.size() <= index) material_ext.resize(index + 1);
     material_ext[index] = e;
+}
+
+void Scene::set_material_normal_scale(uint64_t index, float scale)
+{
+    if (ptx_set_material_normal_scale(ctx_, (uint32_t)index, scale)) ptx_throw(ctx_, "set_material_normal_scale");
 }
 
 uint64_t Scene::add_material(const ptx_material &m)

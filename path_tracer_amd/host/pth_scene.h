@@ -54,6 +54,7 @@ struct Material {
     uint32_t mr_texture = 0;            // metallicRoughnessTexture: bindless index + 1, 0 = none (not under ref quirks)
     uint32_t normal_texture = 0;        // normalTexture (linear), emissiveTexture (sRGB): the same convention
     uint32_t emissive_texture = 0;
+    float normal_scale = 1.0f;          // normalTexture.scale
     uint64_t get_shared_buffer_offset() const { return shared_buffer_index; }
 };
 
@@ -84,6 +85,7 @@ public:
     std::pair<uint64_t, uint64_t> add_indices(const std::vector<uint32_t> &i);
     uint64_t add_material(const ptx_material &m);
     void set_material_ext(uint64_t index, const ptx_material_ext &e);   // build extension
+    void set_material_normal_scale(uint64_t index, float scale);        // build extension: glTF normalTexture.scale
 
     const Geometry *get_geometry(const std::string &ident) const;
     void add_geometry(const std::string &ident, const Geometry &g) { geometries_[ident] = g; }

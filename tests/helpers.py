@@ -90,6 +90,8 @@ def upload(ctx, ing, oracle, options=0, with_material_ext=False):
         mi = ctx.add_material(m)
         if with_material_ext:
             ctx.set_material_ext(mi, ing.material_ext[i])
+            if float(ing.normal_scale[i]) != 1.0:
+                ctx.set_material_normal_scale(mi, ing.normal_scale[i])
     geoms = {}
     for ident, (gid, v_first, v_count, i_first, i_count) in ing.geometries.items():
         fv = ctx.add_vertices(ing.vertices[v_first:v_first + v_count])
@@ -205,7 +207,7 @@ def write_mr_quad_gltf(dirpath, with_maps=False):
            "images": [{"uri": "base.png"}, {"uri": "mr.png"}],
            "buffers": [{"uri": "mrquad.bin", "byteLength": len(blob)}], "bufferViews": views, "accessors": accessors}
     if with_maps:
-        doc["materials"][0]["normalTexture"] = {"index": 2}
+        doc["materials"][0]["normalTexture"] = {"index": 2, "scale": 0.6}
         doc["materials"][1]["emissiveTexture"] = {"index": 3}
         doc["textures"] += [{"source": 2, "sampler": 0}, {"source": 3, "sampler": 1}]
         doc["images"] += [{"uri": "normal.png"}, {"uri": "emit.png"}]

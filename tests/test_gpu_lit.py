@@ -178,6 +178,8 @@ def test_texel_sets_every_mode_against_oracle_and_plain_taps(oracle, gpu_ctx_fac
         if t % 3 != 1:
             ing.textures.append((rng.integers(0, 256, (h, w, 4), dtype=np.uint8), modes[t]))
             ing.material_ext[t]["normal_texture"] = len(ing.textures)
+            if t % 2:
+                ing.normal_scale[t] = np.float32(0.35 + 0.3 * (t % 5))      # glTF normalTexture.scale (ptx_set_material_normal_scale)
         if t % 4 != 2:
             shape = (h + 1, w, 4) if t % 5 == 4 else (h, w, 4)   # every fifth: another size, no set
             ing.textures.append((rng.integers(0, 256, shape, dtype=np.uint8), modes[t]))
@@ -235,6 +237,11 @@ def test_extension_error_paths(gpu_ctx_factory):
         ctx.set_scene_options(4)
     with pytest.raises(capi.PtxError):
         ctx.add_texture(np.zeros((2, 2, 4), np.uint8), 8)
+    ctx.set_material_normal_scale(mi, 0.5)
+    with pytest.raises(capi.PtxError):
+        ctx.set_material_normal_scale(mi + 1, 0.5)
+    with pytest.raises(capi.PtxError):
+        ctx.set_material_normal_scale(mi, float("nan"))
 
 
 def test_host_lit_matches_oracle(oracle):
