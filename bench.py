@@ -447,7 +447,9 @@ def main():
                        "resolution": "%dx%d" % (W, H), "spp_per_step": spp,
                        "max_depth": args.max_depth, "seed": SEED, "geometry": wl["geometry"],
                        "parallelism": "spp-partition x%d, scene+BVH replicated, one RCCL reduce" % world if world > 1 else "single GPU",
-                       "triangles": int(st["bvh_triangles"]), "bvh_nodes": int(st["bvh_nodes"])},
+                       "triangles": int(st["bvh_triangles"]), "bvh_nodes": int(st["bvh_nodes"]),
+                       "paths_per_chunk": int(ctx.get_option(capi.OPTION_TARGET_PATHS)),
+                       "texel_set_bytes": int(ctx.get_option(capi.OPTION_TEXEL_SET_BYTES))},
             "mrays_per_s": round(job_rays / elapsed / 1e6, 1),
             "rays_per_sample": round(job_rays / max(1.0, job_samples), 3),
             "shadow_rays_per_sample": round(st["shadow_rays"] / max(1, st["samples"]), 3), "lights": int(st["lights"]),
