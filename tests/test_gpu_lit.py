@@ -217,6 +217,42 @@ def test_texel_sets_every_mode_against_oracle_and_plain_taps(oracle, gpu_ctx_fac
     assert_images_bit_equal(gpu_render(b, oracle, cam, 96, 96, 1, params=capi.default_params(max_depth=4)), want_ref, "reference integrator beside texel sets")
 
 
+def test_lion_real_2k_maps_lit_host_vs_oracle(oracle):
+    """The reference's scanned lion head with ITS OWN 2048 x 2048 maps -- base colour (sRGB JPEG), tangent-space normal map,
+    occlusion / roughness / metallic map -- through the C++ host's no-ref-quirks glTF import and the lit integrator: one
+    bilinear-or-nearest sampler for all three, so the material gets a texel set (real data at full size), against the
+    oracle-side ingest of the same file (same decoder), and against the plain taps."""
+    import os
+    from helpers import ASSETS, ingest
+    from path_tracer_amd import capi, host
+    W, H, SPP = 288, 162, 2
+    fov = np.deg2rad(np.float32(70.0))
+    imgs = []
+    for sets in (1, 0):
+        r = host.Renderer(W, H, 0)
+        r._ctx().set_option(capi.OPTION_TEXEL_SETS, sets)
+        r.set_ref_quirks(False)
+        r.import_gltf(os.path.join(ASSETS, "lion_head_2k/lion_head_2k.gltf"), (2, 0, 0))
+        r.set_camera([2.0, 0.25, 0.6], host.yaw_quat(0.0), fov, 0.1, 1000.0)
+        r.set_seed(SEED, fixed=True)
+        r.set_params(capi.default_params(max_depth=6, integrator=capi.INTEGRATOR_LIT))
+        r.record_commands(); r.record_commands()
+        r.record_commands_batch(SPP)
+        imgs.append({k: r.read_image(v) for k, v in (("albedo", capi.IMAGE_ALBEDO), ("normal", capi.IMAGE_NORMAL),
+                                                     ("depth", capi.IMAGE_DEPTH), ("ids", capi.IMAGE_PRIMARY_ID))})
+        set_bytes = r._ctx().get_option(capi.OPTION_TEXEL_SET_BYTES)
+        assert (set_bytes > 100 << 20) if sets else (set_bytes == 0), set_bytes        # 2050 x 2050 entries x 32 B
+        r.close()
+    ing = ingest(("lion_head_2k/lion_head_2k.gltf", (2, 0, 0)), decode_image=host.decode_image, ref_quirks=False)
+    assert ing.material_ext["normal_texture"][0] and ing.material_ext["mr_texture"][0] and ing.materials["has_base_texture"][0]
+    sc = oracle.scene_from_ingest(ing, options=oracle.SCENE_WORLD_NORMALS | oracle.SCENE_TEXTURE_TIMES_FACTOR, with_material_ext=True)
+    cam = oracle.camera_matrices([2.0, 0.25, 0.6], oracle.yaw_quat(0), fov, W / H, 0.1, 1000.0)
+    want = sc.render(cam, W, H, SPP, SEED, params=oracle.default_params(max_depth=6, integrator=oracle.INTEGRATOR_LIT))
+    assert want["stats"]["textured_hits"] > 10000
+    assert_images_bit_equal(imgs[0], want, "lion, real 2k maps, texel set")
+    assert_images_bit_equal(imgs[1], want, "lion, real 2k maps, plain taps")
+
+
 def test_extension_error_paths(gpu_ctx_factory):
     from path_tracer_amd import capi
     ctx = gpu_ctx_factory()
