@@ -33,6 +33,29 @@ def test_lit_golden_image(oracle):
     assert np.array_equal(r2["albedo"].view(np.uint32), r["albedo"].view(np.uint32))
 
 
+def test_lit_textured_golden_image(oracle, tmp_path):
+    """The textured lit paths of the oracle (base colour, metallic-roughness, normal map with normalTexture.scale 0.6, emissive
+    map) against the committed vector (tests/golden/make_golden_lit.py): a change to raygen_pixel_lit, to the texture
+    fetch or to the glTF ingest shows up here before it can move both sides of a GPU parity test together."""
+    from helpers import write_mr_quad_gltf
+    from oracle.gltf_ingest import IngestedScene
+    g = np.load(os.path.join(GOLDEN, "mr_quad_maps_48x48_4spp_depth6.npz"))
+    ing = IngestedScene(ref_quirks=False)
+    ing.import_gltf(write_mr_quad_gltf(str(tmp_path), with_maps=True))
+    assert np.array_equal(ing.normal_scale, g["normal_scale"]) and float(ing.normal_scale[0]) == np.float32(0.6)
+    sc = oracle.scene_from_ingest(ing, options=oracle.SCENE_WORLD_NORMALS | oracle.SCENE_TEXTURE_TIMES_FACTOR, with_material_ext=True)
+    cam = oracle.camera_matrices([0.0, 1.2, 3.5], oracle.yaw_quat(0), np.deg2rad(np.float32(55.0)), 1.0, 0.1, 1000.0)
+    r = sc.render(cam, 48, 48, 4, SEED, params=oracle.default_params(max_depth=6, integrator=oracle.INTEGRATOR_LIT))
+    for k in ("albedo", "normal", "depth", "ids"):
+        assert np.array_equal(np.ascontiguousarray(r[k]).view(np.uint32), np.ascontiguousarray(g[k]).view(np.uint32)), k
+    assert [r["stats"][k] for k in ("rays", "hits", "samples", "shadow_rays", "textured_hits")] == [int(x) for x in g["stats"]]
+    # and the scale matters: the same scene with scale 1 gives other normals
+    ing.normal_scale[:] = 1.0
+    r1 = oracle.scene_from_ingest(ing, options=oracle.SCENE_WORLD_NORMALS | oracle.SCENE_TEXTURE_TIMES_FACTOR, with_material_ext=True).render(
+        cam, 48, 48, 1, SEED, params=oracle.default_params(max_depth=2, integrator=oracle.INTEGRATOR_LIT))
+    assert not np.array_equal(r1["normal"].view(np.uint32), np.ascontiguousarray(g["normal"]).view(np.uint32))
+
+
 def test_light_table(oracle):
     sc = _lit_scene(oracle)
     lights = sc.lights()
